@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""sympy -> C generator for the per-system dynamics headers.
+
+Replaces ``sp.lambdify`` of f_disc / A_disc / B_disc
+(/root/reference/python/symbolic_dynamics.py:23-25 and :88-90).
+
+How parity with the lambdified numpy callables is kept:
+the generator does NOT print the sympy tree with its own printer.  It asks
+sympy for the exact python source ``lambdify`` would execute, parses that
+source with ``ast`` and re-emits the same expression tree in C:
+
+* same association of every ``+ - * /`` (python is left-associative, so is the
+  emitted, fully parenthesised C),
+* same literals (15-significant-digit decimals printed by sympy's StrPrinter;
+  ``1/2`` stays a division of two exact constants),
+* ``x**2`` becomes ``x*x`` (numpy's scalar pow is within 1 ulp of it),
+* ``sin/cos/tan`` calls are hoisted into named temporaries, one per distinct
+  argument, so host libm / device ocml are called once per argument.
+
+Common sub-expression elimination is left to the C compiler, which is value
+preserving under ``-ffp-contract=off`` (no re-association, no contraction).
+
+Output: ``ilqr_amd/csrc/dynamics/<system>.h``.  The includer defines
+``ILQR_DYN_FN`` (function qualifiers) and ``ILQR_DYN_CONST`` (qualifier of the
+sparsity tables) -- hipcc for gfx950 in ``ilqr_hip.hip``, gcc in ``oracle/``.
+The generated headers are committed: the GPU box never runs sympy.
+"""
+import ast
+import inspect
+import os
+import sys
+
+import sympy as sp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import models  # noqa: E402
+
+OUT_DIR = os.path.join(HERE, '..', 'ilqr_amd', 'csrc', 'dynamics')
+
+_FUNCS = {'sin': 'sin', 'cos': 'cos', 'tan': 'tan', 'sqrt': 'sqrt', 'exp': 'exp', 'log': 'log'}
+
+
+class _Emitter:
+    """Translate one lambdify-generated function body to C statements."""
+
+    def __init__(self, src):
+        self.tree = ast.parse(src)
+        fn = self.tree.body[0]
+        assert isinstance(fn, ast.FunctionDef)
+        argnames = [a.arg for a in fn.args.args]
+        assert len(argnames) == 4, argnames
+        carg = {argnames[0]: 'x', argnames[1]: 'u', argnames[3]: 'p'}
+        self.names = {argnames[2]: 'dt'}
+        self.ret = None
+        for st in fn.body:
+            if isinstance(st, ast.Assign):
+                tgt, val = st.targets[0], st.value
+                assert isinstance(val, ast.Name) and val.id in carg, ast.dump(st)
+                for i, el in enumerate(tgt.elts):
+                    self.names[el.id] = '%s[%d]' % (carg[val.id], i)
+            elif isinstance(st, ast.Return):
+                self.ret = st.value
+        assert self.ret is not None
+        self.trig = {}       # "sin(x[1])" -> temp name
+        self.trig_defs = []  # ordered definitions
+
+    def elements(self):
+        call = self.ret
+        assert isinstance(call, ast.Call) and call.func.id == 'array'
+        rows = call.args[0].elts
+        out = []
+        for r in rows:
+            out.append([self.expr(e) for e in r.elts])
+        return out
+
+    def expr(self, e):
+        if isinstance(e, ast.BinOp):
+            if isinstance(e.op, ast.Pow):
+                return self.power(e.left, e.right)
+            op = {ast.Add: '+', ast.Sub: '-', ast.Mult: '*', ast.Div: '/'}[type(e.op)]
+            return '(%s %s %s)' % (self.expr(e.left), op, self.expr(e.right))
+        if isinstance(e, ast.UnaryOp):
+            if isinstance(e.op, ast.USub):
+                return '(-%s)' % self.expr(e.operand)
+            if isinstance(e.op, ast.UAdd):
+                return self.expr(e.operand)
+        if isinstance(e, ast.Constant):
+            v = e.value
+            if isinstance(v, int):
+                return '%d.0' % v
+            return repr(float(v))
+        if isinstance(e, ast.Name):
+            return self.names[e.id]
+        if isinstance(e, ast.Call):
+            fname = e.func.id if isinstance(e.func, ast.Name) else e.func.attr
+            assert fname in _FUNCS and len(e.args) == 1, ast.dump(e)
+            key = '%s(%s)' % (_FUNCS[fname], self.expr(e.args[0]))
+            if fname in ('sin', 'cos', 'tan'):
+                if key not in self.trig:
+                    t = 'tr%d' % len(self.trig)
+                    self.trig[key] = t
+                    self.trig_defs.append('const double %s = %s;' % (t, key))
+                return self.trig[key]
+            return key
+        raise NotImplementedError(ast.dump(e))
+
+    def power(self, base, expo):
+        b = self.expr(base)
+        neg = False
+        if isinstance(expo, ast.UnaryOp) and isinstance(expo.op, ast.USub):
+            neg, expo = True, expo.operand
+        assert isinstance(expo, ast.Constant), ast.dump(expo)
+        v = expo.value
+        if isinstance(v, int) and 1 <= v <= 4:
+            r = {1: b, 2: 'ilqr_dyn_sq(%s)' % b, 3: 'ilqr_dyn_cube(%s)' % b,
+                 4: 'ilqr_dyn_sq(ilqr_dyn_sq(%s))' % b}[v]
+        elif float(v) == 0.5:
+            r = 'sqrt(%s)' % b
+        else:
+            r = 'pow(%s, %r)' % (b, float(v))
+        return '(1.0 / %s)' % r if neg else r
+
+
+def _pattern(mat):
+    """'0' structural zero, '1' structural one, 'x' anything else (row-major)."""
+    out = []
+    for i in range(mat.shape[0]):
+        for j in range(mat.shape[1]):
+            e = mat[i, j]
+            out.append('0' if e == 0 else ('1' if e == 1 else 'x'))
+    return ''.join(out)
+
+
+def _function(model, what, mat):
+    args = (model.states, model.inputs, model.dt, model.parameters)
+    src = inspect.getsource(sp.lambdify(args, mat))
+    em = _Emitter(src)
+    els = em.elements()
+    lines = ['ILQR_DYN_FN void ilqr_dyn_%s_%s(const double* x, const double* u, const double dt, '
+             'const double* p, double* out)' % (model.name, what), '{']
+    lines.append('    (void)x; (void)u; (void)dt; (void)p;')
+    for d in em.trig_defs:
+        lines.append('    ' + d)
+    k = 0
+    for row in els:
+        for e in row:
+            lines.append('    out[%d] = %s;' % (k, e))
+            k += 1
+    lines.append('}')
+    return '\n'.join(lines), src
+
+
+def generate(name):
+    model = models.BUILDERS[name]()
+    n, m, npar = model.n, model.m, model.n_params
+    up = name.upper()
+    parts = []
+    parts.append('/* GENERATED by codegen/gen_dynamics.py from codegen/models.py:%s() -- do not edit.\n'
+                 ' * Forward-Euler discretised dynamics and Jacobians of the %s system, emitted from the\n'
+                 ' * python source sympy.lambdify would run (same expression tree, same literals).\n'
+                 ' * Reference: /root/reference/python/symbolic_dynamics.py:23-25,88-90 (lambdify call sites).\n'
+                 ' * Row-major: f out[n], A out[n*n] (A[i][j] = out[i*n+j]), B out[n*m].\n'
+                 ' * The includer defines ILQR_DYN_FN and ILQR_DYN_CONST and must compile with -ffp-contract=off. */'
+                 % (name, name))
+    parts.append('#ifndef ILQR_DYN_%s_H\n#define ILQR_DYN_%s_H' % (up, up))
+    parts.append('#define ILQR_DYN_%s_ID %d\n#define ILQR_DYN_%s_N %d\n#define ILQR_DYN_%s_M %d\n#define ILQR_DYN_%s_NP %d'
+                 % (up, models.SYSTEM_IDS[name], up, n, up, m, up, npar))
+    parts.append('#ifndef ILQR_DYN_HELPERS\n#define ILQR_DYN_HELPERS\n'
+                 'ILQR_DYN_FN double ilqr_dyn_sq(const double a) { return a * a; }\n'
+                 'ILQR_DYN_FN double ilqr_dyn_cube(const double a) { return (a * a) * a; }\n#endif')
+    parts.append('/* sparsity of the Jacobians: \'0\' structural zero, \'1\' structural one, \'x\' general */')
+    parts.append('ILQR_DYN_CONST char ilqr_dyn_%s_A_pat[%d] = "%s";' % (name, n * n + 1, _pattern(model.A_disc)))
+    parts.append('ILQR_DYN_CONST char ilqr_dyn_%s_B_pat[%d] = "%s";' % (name, n * m + 1, _pattern(model.B_disc)))
+    srcs = {}
+    for what, mat in (('f', model.f_disc), ('A', model.A_disc), ('B', model.B_disc)):
+        code, src = _function(model, what, mat)
+        parts.append(code)
+        srcs[what] = src
+    parts.append('#endif')
+    text = '\n\n'.join(parts) + '\n'
+    path = os.path.join(OUT_DIR, name + '.h')
+    with open(path, 'w') as fh:
+        fh.write(text)
+    return path, srcs
+
+
+def main():
+    os.makedirs(OUT_DIR, exist_ok=True)
+    names = sys.argv[1:] or list(models.BUILDERS)
+    for name in names:
+        path, _ = generate(name)
+        print('wrote', os.path.relpath(path), os.path.getsize(path), 'bytes')
+
+
+if __name__ == '__main__':
+    main()

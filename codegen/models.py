@@ -1,0 +1,152 @@
+"""Symbolic models for the four systems of the hot path (own sympy code).
+
+Each builder returns a ``Model`` whose ``f_disc``/``A_disc``/``B_disc`` are the
+forward-Euler discretised dynamics and their Jacobians, exactly the triple the
+reference lambdifies:
+
+* pendulum   -- /root/reference/python/symbolic_dynamics.py:5-26  (the reference
+  text has the typo ``sp.sp.sin`` at :12, so it cannot run; the expression
+  here is the same one written with ``sp.sin``)
+* acrobot    -- /root/reference/python/symbolic_dynamics.py:28-92  (same
+  construction sequence -- simplify(M), Christoffel loop with python-float
+  ``1/2``, ``M.inv()`` -- so sympy produces the same expression tree and the
+  same 15-digit literals when printed)
+* cartpole   -- spec: matlab/smooth-ilqr/symbolic_dynamics_cartpole.m:2-22
+* quadcopter -- spec: matlab/smooth-ilqr/symbolic_dynamics_quadcopter.m:3-51
+
+The MATLAB files are specifications only (read as text; nothing here executes
+them).  This module needs sympy and is used by ``codegen/gen_dynamics.py`` and
+``tools/make_golden.py``; nothing on the GPU box imports it.
+"""
+from dataclasses import dataclass
+
+import sympy as sp
+from sympy.matrices import Matrix
+
+
+@dataclass
+class Model:
+    name: str
+    states: Matrix
+    inputs: Matrix
+    dt: sp.Symbol
+    parameters: Matrix
+    f_disc: Matrix
+    A_disc: Matrix
+    B_disc: Matrix
+
+    @property
+    def n(self):
+        return self.states.shape[0]
+
+    @property
+    def m(self):
+        return self.inputs.shape[0]
+
+    @property
+    def n_params(self):
+        return self.parameters.shape[0]
+
+    def lambdify(self):
+        """The (f, A, B) numpy callables the reference would build (symbolic_dynamics.py:23-25)."""
+        args = (self.states, self.inputs, self.dt, self.parameters)
+        return (sp.lambdify(args, self.f_disc),
+                sp.lambdify(args, self.A_disc),
+                sp.lambdify(args, self.B_disc))
+
+
+def _finish(name, states, inputs, dt, parameters, f):
+    f_disc = states + f * dt
+    A_disc = f_disc.jacobian(states)
+    B_disc = f_disc.jacobian(inputs)
+    return Model(name, states, inputs, dt, parameters, f_disc, A_disc, B_disc)
+
+
+def pendulum():
+    m, g, L, theta, theta_dot, u, dt = sp.symbols('m g L theta theta_dot u dt')
+    inputs = Matrix([u])
+    states = Matrix([theta, theta_dot])
+    f = Matrix([theta_dot, (u - m * g * L * sp.sin(theta)) / (m * L * L)])
+    return _finish('pendulum', states, inputs, dt, Matrix([m, g, L]), f)
+
+
+def acrobot():
+    q1, q2, q1_dot, q2_dot = sp.symbols('q1 q2 q1_dot q2_dot')
+    tau_2 = sp.symbols('tau_2')
+    m1, L1, m2, L2, g, dt = sp.symbols('m1 L1 m2 L2 g dt ')
+    q = Matrix([[q1], [q2]])
+    q_dot = Matrix([[q1_dot], [q2_dot]])
+    tau = Matrix([[0], [tau_2]])
+    states = Matrix([[q], [q_dot]])
+    inputs = Matrix([tau_2])
+    # generalised inertia of each link (python float 1/12 on purpose: it becomes a sympy Float)
+    M1 = Matrix([[m1, 0, 0], [0, m1, 0], [0, 0, 1 / 12 * m1 * L1 * L1]])
+    M2 = Matrix([[m2, 0, 0], [0, m2, 0], [0, 0, 1 / 12 * m2 * L2 * L2]])
+    # body Jacobians
+    Jb_sL1 = Matrix([[0, 0], [L1 / 2, 0], [1, 0]])
+    Jb_sL2 = Matrix([[L1 * sp.sin(q2), 0], [L1 * sp.cos(q2) + L2 / 2, L2 / 2], [1, 1]])
+    M = sp.simplify(Jb_sL1.T @ M1 @ Jb_sL1 + Jb_sL2.T @ M2 @ Jb_sL2)
+    nq = 2
+    C = sp.zeros(nq, nq)
+    for ii in range(nq):
+        for jj in range(nq):
+            for kk in range(nq):
+                C[ii, jj] = C[ii, jj] + 1 / 2 * (sp.diff(M[ii, jj], q[kk]) + sp.diff(M[ii, kk], q[jj])
+                                                 - sp.diff(M[jj, kk], q[ii])) * q_dot[kk]
+    V = Matrix([(m1 * g * L1 / 2 * sp.sin(q1) + m2 * g * (L1 * sp.sin(q1) + L2 / 2 * sp.sin(q1 + q2)))])
+    N = V.jacobian(q).T
+    Y = tau
+    f = Matrix([q_dot, M.inv() @ (Y - N - C @ q_dot)])
+    return _finish('acrobot', states, inputs, dt, Matrix([m1, L1, m2, L2, g]), f)
+
+
+def cartpole():
+    mc, mp, ll, g, x, x_dot, theta, theta_dot, u, dt = sp.symbols('mc mp ll g x x_dot theta theta_dot u dt', real=True)
+    inputs = Matrix([u])
+    states = Matrix([x, theta, x_dot, theta_dot])
+    s, c = sp.sin(theta), sp.cos(theta)
+    f = Matrix([
+        x_dot,
+        theta_dot,
+        1 / (mc + mp * s**2) * (u + mp * s * (ll * theta_dot**2 + g * c)),
+        1 / (ll * (mc + mp * s**2)) * (-u * c - mp * ll * theta_dot**2 * c * s - (mc + mp) * g * s),
+    ])
+    return _finish('cartpole', states, inputs, dt, Matrix([mc, mp, ll, g]), f)
+
+
+def quadcopter():
+    px, py, pz, u, v, w, phi, theta, psi, p, q, r, dt = sp.symbols('px py pz u v w phi theta psi p q r dt', real=True)
+    delta_l, delta_r, delta_b, delta_f = sp.symbols('delta_l delta_r delta_b delta_f', real=True)
+    J_x, J_y, J_z, m, g, ell, k_1, k_2 = sp.symbols('J_x J_y J_z m g ell k_1 k_2', real=True)
+    sin, cos, tan = sp.sin, sp.cos, sp.tan
+    F_l, F_r, F_b, F_f = k_1 * delta_l, k_1 * delta_r, k_1 * delta_b, k_1 * delta_f
+    tau_l, tau_r, tau_b, tau_f = k_2 * delta_l, k_2 * delta_r, k_2 * delta_b, k_2 * delta_f
+    F = F_f + F_r + F_b + F_l
+    tau_phi = ell * (F_l - F_r)
+    tau_theta = ell * (F_f - F_b)
+    tau_psi = -tau_f + tau_r - tau_b + tau_l
+    R = Matrix([
+        [cos(theta) * cos(psi), sin(phi) * sin(theta) * cos(psi) - cos(phi) * sin(psi),
+         cos(phi) * sin(theta) * cos(psi) + sin(phi) * sin(psi)],
+        [cos(theta) * sin(psi), sin(phi) * sin(theta) * sin(psi) + cos(phi) * cos(psi),
+         cos(phi) * sin(theta) * sin(psi) - sin(phi) * cos(psi)],
+        [sin(theta), -sin(phi) * cos(theta), -cos(phi) * cos(theta)]])
+    trans_vel = R * Matrix([u, v, w])
+    trans_vel[2] = -trans_vel[2]
+    trans_accel = (Matrix([r * v - q * w, p * w - r * u, q * u - p * v])
+                   + Matrix([-g * sin(theta), g * cos(theta) * sin(phi), g * cos(theta) * cos(phi)])
+                   + (1 / m) * Matrix([0, 0, -F]))
+    angular_vel = Matrix([[1, sin(phi) * tan(theta), cos(phi) * tan(theta)],
+                          [0, cos(phi), -sin(phi)],
+                          [0, sin(phi) / cos(theta), cos(phi) / cos(theta)]]) * Matrix([p, q, r])
+    angular_accel = (Matrix([(J_y - J_z) / J_x * q * r, (J_z - J_x) / J_y * p * r, (J_x - J_y) / J_z * p * q])
+                     + Matrix([1 / J_x * tau_phi, 1 / J_y * tau_theta, 1 / J_z * tau_psi]))
+    states = Matrix([px, py, pz, phi, theta, psi, u, v, w, p, q, r])
+    inputs = Matrix([delta_f, delta_r, delta_b, delta_l])
+    f = Matrix([trans_vel, angular_vel, trans_accel, angular_accel])
+    return _finish('quadcopter', states, inputs, dt, Matrix([J_x, J_y, J_z, m, g, ell, k_1, k_2]), f)
+
+
+BUILDERS = {'pendulum': pendulum, 'acrobot': acrobot, 'cartpole': cartpole, 'quadcopter': quadcopter}
+# system ids are part of the C-ABI (include/ilqr_hip.h)
+SYSTEM_IDS = {'pendulum': 0, 'acrobot': 1, 'cartpole': 2, 'quadcopter': 3}
