@@ -1,0 +1,18 @@
+"""ilqr_amd -- batched iLQR / LTV-LQR for AMD MI355X behind the python API of Kongx231/ilqr.
+
+    from ilqr_amd import ilqr, ltvlqr, symbolic_dynamics_acrobot
+
+``ilqr`` and ``ltvlqr`` keep the reference's signatures (python/ilqr.py:5, python/ltvlqr.py:3); the dynamics
+triples come from ``symbolic_dynamics_<system>()`` (python/symbolic_dynamics.py:5,28).  Everything is computed by
+hand-written HIP kernels for gfx950 in ``libilqr_hip.so`` (C ABI: include/ilqr_hip.h); importing this package
+does not need a GPU, calling it does.
+"""
+from . import _lib
+from ._lib import IlqrHipError, Workspace, lib
+from .ilqr import ilqr
+from .ltvlqr import ltvlqr
+from .symbolic_dynamics import (CompiledDynamics, symbolic_dynamics_acrobot, symbolic_dynamics_cartpole,
+                                symbolic_dynamics_pendulum, symbolic_dynamics_quadcopter)
+
+__all__ = ['ilqr', 'ltvlqr', 'symbolic_dynamics_pendulum', 'symbolic_dynamics_acrobot', 'symbolic_dynamics_cartpole',
+           'symbolic_dynamics_quadcopter', 'CompiledDynamics', 'Workspace', 'IlqrHipError', 'lib']

@@ -1,0 +1,1616 @@
+// ilqr_hip.hip -- batched iLQR / LTV-LQR hot path for AMD MI355X (gfx950, CDNA4), fp64.
+//
+// What is here (reference = Kongx231/ilqr, python/ilqr.py and python/ltvlqr.py):
+//   k_rollout     ilqr.rollout            ilqr.py:30-47  (+ compute_cost :49-62 fused)
+//   k_backward    ilqr.backwards_pass     ilqr.py:64-135 (+ the "optimal" stop test :175)
+//   k_linesearch  the while loop of solve ilqr.py:180-202: W line-search trials per problem run concurrently
+//                 on W adjacent lanes, the first accepted trial is found with a ballot over the lane group
+//   k_forward     ilqr.forwards_pass      ilqr.py:137-158 (also the accept step :194-199, re-rolling the winner)
+//   k_ltvlqr      ltvlqr                  ltvlqr.py:3-28
+//   k_dynamics    the lambdified f/A/B    symbolic_dynamics.py:23-25,88-90
+//   k_pack/k_unpack  reference layout (B,T,C) <-> tiled SoA [b/64][T][C][b%64]
+//
+// Design: problems are independent, the horizon is sequential.  One lane owns one problem in
+// the backward / forward / ltvlqr kernels, with V_xx, V_x, A, B, Q_* held in VGPRs (n <= 4: no LDS, no
+// cross-lane traffic); a wave streams its own contiguous tile of 64 problems so every global access is a
+// 512-byte coalesced row.  No MFMA: the products are n x n with n <= 12, fp64, and serially dependent in time.
+// The translation unit is compiled with -ffp-contract=off; fused multiply-adds appear only where written
+// (__builtin_fma in the small dense products), never inside the generated dynamics.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/ilqr_hip.h"
+
+#define ILQR_DYN_FN __device__ __forceinline__
+#define ILQR_DYN_CONST static constexpr
+#include "dynamics/pendulum.h"
+#include "dynamics/acrobot.h"
+#include "dynamics/cartpole.h"
+#include "dynamics/quadcopter.h"
+
+namespace {
+
+constexpr int TILE = 64;          // problems per tile = lanes per wavefront
+constexpr int MAX_TRIALS = 64;    // line-search trials kept in the alpha table
+constexpr int N_KERNEL_IDS = 8;
+
+// ------------------------------------------------------------------------------------------------
+// systems
+// ------------------------------------------------------------------------------------------------
+#define ILQR_DEFINE_SYSTEM(NAME, UP)                                                                              \
+    struct Sys_##NAME {                                                                                           \
+        static constexpr int n = ILQR_DYN_##UP##_N, m = ILQR_DYN_##UP##_M, np = ILQR_DYN_##UP##_NP;               \
+        static constexpr int id = ILQR_DYN_##UP##_ID;                                                             \
+        static __device__ __forceinline__ char a_kind(int i) { return ilqr_dyn_##NAME##_A_pat[i]; }               \
+        static __device__ __forceinline__ char b_kind(int i) { return ilqr_dyn_##NAME##_B_pat[i]; }               \
+        static __device__ __forceinline__ void f(const double* x, const double* u, double dt, const double* p,   \
+                                                 double* o) { ilqr_dyn_##NAME##_f(x, u, dt, p, o); }              \
+        static __device__ __forceinline__ void A(const double* x, const double* u, double dt, const double* p,   \
+                                                 double* o) { ilqr_dyn_##NAME##_A(x, u, dt, p, o); }              \
+        static __device__ __forceinline__ void B(const double* x, const double* u, double dt, const double* p,   \
+                                                 double* o) { ilqr_dyn_##NAME##_B(x, u, dt, p, o); }              \
+    };
+ILQR_DEFINE_SYSTEM(pendulum, PENDULUM)
+ILQR_DEFINE_SYSTEM(acrobot, ACROBOT)
+ILQR_DEFINE_SYSTEM(cartpole, CARTPOLE)
+ILQR_DEFINE_SYSTEM(quadcopter, QUADCOPTER)
+
+struct SysInfo { const char* name; int n, m, np; };
+const SysInfo SYSTEMS[4] = {{"pendulum", 2, 1, 3}, {"acrobot", 4, 1, 5}, {"cartpole", 4, 1, 4}, {"quadcopter", 12, 4, 8}};
+
+// ------------------------------------------------------------------------------------------------
+// kernel arguments
+// ------------------------------------------------------------------------------------------------
+struct KArgs {
+    int N;                 // time steps
+    int it;                // outer iteration index (trace row)
+    int n_iter;            // rows in trace
+    int zero_first;
+    int n_trials;          // line-search trials with alpha > low_learning_rate
+    int state_rows;        // rows per problem in X (N+1)
+    long long n_tiles;
+    double dt, low_red, armijo_thr, quu_reg;
+    double* X;             // [tile][state_rows][n][64]
+    double* U;             // [tile][N][m][64]
+    double* KFB;           // [tile][N][m*n][64]
+    double* KFF;           // [tile][N][m][64]
+    double* XO;            // forward outputs (may alias X/U)
+    double* UO;
+    const double* INIT;    // [tile][n][64]
+    const double* TARGET;  // [tile][n][64]
+    const double* PARAMS;  // [tile][np][64]
+    const double* WTS;     // Qk[n*n], Rk[m*m], QT[n*n]
+    const double* alphas;  // [MAX_TRIALS] alpha_j by repeated multiplication
+    const double* alpha_pp;// per-problem alpha (forward API) or nullptr
+    double* cost;          // [Bpad]
+    double* new_cost;      // [Bpad]
+    double* dJ;            // [tile][3][64]: total, grad, hess
+    int* active;           // [Bpad]
+    int* iters;
+    int* status;
+    int* acc_j;
+    int* ls_rounds;
+    int* accepts;
+    double* trace;         // [tile][n_iter][6][64] or nullptr
+    long long Bpad;
+};
+
+// ------------------------------------------------------------------------------------------------
+// small dense helpers.  Every loop is fully unrolled so all arrays live in VGPRs; `kind` is the
+// compile-time sparsity class of the Jacobian entry ('0' zero, '1' one, 'x' general): after unrolling
+// the tests fold away and structurally zero / unit entries cost nothing.  Skipping an exact-zero product
+// or multiplying by an exact one does not change any rounding.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void acc_term(double& s, bool& first, char kind, double a, double b)
+{
+    if (kind == '0') return;
+    if (kind == '1') s = first ? b : s + b;
+    else s = first ? a * b : __builtin_fma(a, b, s);
+    first = false;
+}
+
+template <class S>
+struct Riccati {
+    static constexpr int n = S::n, m = S::m;
+
+    // inverse of the m x m matrix Q (row-major).  m == 1: reciprocal (what LAPACK getri does for 1x1).
+    // m > 1: Cholesky L L^T, inv = L^-T L^-1.  Returns false when Q is not positive definite / not finite.
+    static __device__ __forceinline__ bool inv_spd(const double (&Q)[m * m], double (&Qi)[m * m])
+    {
+        if constexpr (m == 1) {
+            Qi[0] = 1.0 / Q[0];
+            return Q[0] != 0.0;
+        } else {
+            double L[m * m], Li[m * m];
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < m; ++j) {
+                double d = Q[j * m + j];
+#pragma unroll
+                for (int q = 0; q < j; ++q) d = __builtin_fma(-L[j * m + q], L[j * m + q], d);
+                ok = ok && (d > 0.0);
+                const double ljj = sqrt(d);
+                L[j * m + j] = ljj;
+                const double r = 1.0 / ljj;
+#pragma unroll
+                for (int i = j + 1; i < m; ++i) {
+                    double s = Q[i * m + j];
+#pragma unroll
+                    for (int q = 0; q < j; ++q) s = __builtin_fma(-L[i * m + q], L[j * m + q], s);
+                    L[i * m + j] = s * r;
+                }
+            }
+            // Li = L^-1 (lower triangular)
+#pragma unroll
+            for (int j = 0; j < m; ++j) {
+                Li[j * m + j] = 1.0 / L[j * m + j];
+#pragma unroll
+                for (int i = j + 1; i < m; ++i) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int q = j; q < i; ++q) s = __builtin_fma(-L[i * m + q], Li[q * m + j], s);
+                    Li[i * m + j] = s / L[i * m + i];
+                }
+            }
+            // inv = Li^T Li
+#pragma unroll
+            for (int i = 0; i < m; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int q = i; q < m; ++q) s = __builtin_fma(Li[q * m + i], Li[q * m + j], s);
+                    Qi[i * m + j] = s;
+                    Qi[j * m + i] = s;
+                }
+            return ok;
+        }
+    }
+
+    // One step of ilqr.backwards_pass (ilqr.py:84-125).  A, Bm: Jacobians at (x_t,u_t).  Updates Vx, Vxx in place,
+    // returns k, K and the step's (grad, hess) expected-reduction terms.
+    static __device__ __forceinline__ bool step(const double (&A)[n * n], const double (&Bm)[n * m], const double (&u)[m],
+                                                const double (&Qk)[n * n], const double (&Rk)[m * m], double quu_reg,
+                                                double (&Vx)[n], double (&Vxx)[n * n], double (&k)[m], double (&K)[m * n],
+                                                double& g_out, double& h_out)
+    {
+        double Qx[n], Qu[m], BtV[m * n], Qux[m * n], Quu[m * m], Qxx[n * n], Quu_inv[m * m];
+        // :99  Q_x = A.T @ V_x   (l_x = Q_k @ 0 = 0)
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double s = 0.0; bool first = true;
+#pragma unroll
+            for (int r = 0; r < n; ++r) acc_term(s, first, S::a_kind(r * n + i), A[r * n + i], Vx[r]);
+            Qx[i] = s;
+        }
+        // :93,:100  Q_u = R_k @ u + B.T @ V_x
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+            double lu = 0.0;
+#pragma unroll
+            for (int l = 0; l < m; ++l) lu = __builtin_fma(Rk[j * m + l], u[l], lu);
+            double s = 0.0; bool first = true;
+#pragma unroll
+            for (int r = 0; r < n; ++r) acc_term(s, first, S::b_kind(r * m + j), Bm[r * m + j], Vx[r]);
+            Qu[j] = lu + s;
+        }
+        // B.T @ V_xx
+#pragma unroll
+        for (int j = 0; j < m; ++j)
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::b_kind(r * m + j), Bm[r * m + j], Vxx[r * n + c]);
+                BtV[j * n + c] = s;
+            }
+        // :101  Q_ux = (B.T V_xx) A ; :102  Q_uu = R + (B.T V_xx) B
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::a_kind(r * n + c), A[r * n + c], BtV[j * n + r]);
+                Qux[j * n + c] = s;
+            }
+#pragma unroll
+            for (int l = 0; l < m; ++l) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::b_kind(r * m + l), Bm[r * m + l], BtV[j * n + r]);
+                Quu[j * m + l] = Rk[j * m + l] + s;
+            }
+            Quu[j * m + j] += quu_reg;
+        }
+        // :103  Q_xx = Q_k + (A.T V_xx) A, one row of A.T V_xx at a time
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double row[n];
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::a_kind(r * n + i), A[r * n + i], Vxx[r * n + c]);
+                row[c] = s;
+            }
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::a_kind(r * n + c), A[r * n + c], row[r]);
+                Qxx[i * n + c] = Qk[i * n + c] + s;
+            }
+        }
+        // :106-108  gains
+        const bool ok = inv_spd(Quu, Quu_inv);
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < m; ++l) s = __builtin_fma(-Quu_inv[j * m + l], Qu[l], s);
+            k[j] = s;
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double t = 0.0;
+#pragma unroll
+                for (int l = 0; l < m; ++l) t = __builtin_fma(-Quu_inv[j * m + l], Qux[l * n + c], t);
+                K[j * n + c] = t;
+            }
+        }
+        // :115-116  expected reduction terms
+        double g = 0.0, h = 0.0;
+#pragma unroll
+        for (int j = 0; j < m; ++j) g = __builtin_fma(-Qu[j], k[j], g);
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < m; ++i) s = __builtin_fma(0.5 * k[i], Quu[i * m + j], s);
+            h = __builtin_fma(s, k[j], h);
+        }
+        g_out = g; h_out = h;
+        // :124-125  value function update (four-term forms, no symmetrisation)
+        double KtQuu[n * m];
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+#pragma unroll
+            for (int l = 0; l < m; ++l) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < m; ++j) s = __builtin_fma(K[j * n + i], Quu[j * m + l], s);
+                KtQuu[i * m + l] = s;
+            }
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double v1 = 0.0, v2 = 0.0, v3 = 0.0;
+#pragma unroll
+            for (int l = 0; l < m; ++l) v1 = __builtin_fma(KtQuu[i * m + l], k[l], v1);
+#pragma unroll
+            for (int j = 0; j < m; ++j) v2 = __builtin_fma(K[j * n + i], Qu[j], v2);
+#pragma unroll
+            for (int j = 0; j < m; ++j) v3 = __builtin_fma(Qux[j * n + i], k[j], v3);
+            Vx[i] = ((Qx[i] + v1) + v2) + v3;
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+                for (int j = 0; j < m; ++j) t1 = __builtin_fma(Qux[j * n + i], K[j * n + c], t1);
+#pragma unroll
+                for (int j = 0; j < m; ++j) t2 = __builtin_fma(K[j * n + i], Qux[j * n + c], t2);
+#pragma unroll
+                for (int l = 0; l < m; ++l) t3 = __builtin_fma(KtQuu[i * m + l], K[l * n + c], t3);
+                Vxx[i * n + c] = ((Qxx[i * n + c] + t1) + t2) + t3;
+            }
+        }
+        return ok;
+    }
+};
+
+// stage cost of compute_cost (ilqr.py:56): (u^T R) u
+template <int m>
+__device__ __forceinline__ double input_cost(const double (&u)[m], const double (&Rk)[m * m])
+{
+    double c = 0.0;
+#pragma unroll
+    for (int j = 0; j < m; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < m; ++i) s = __builtin_fma(u[i], Rk[i * m + j], s);
+        c = __builtin_fma(s, u[j], c);
+    }
+    return c;
+}
+// terminal cost (ilqr.py:59-60): d = target - x_N, (d^T Q_T) d
+template <int n>
+__device__ __forceinline__ double terminal_cost(const double (&x)[n], const double (&target)[n], const double (&QT)[n * n])
+{
+    double d[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) d[i] = target[i] - x[i];
+    double c = 0.0;
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) s = __builtin_fma(d[i], QT[i * n + j], s);
+        c = __builtin_fma(s, d[j], c);
+    }
+    return c;
+}
+
+template <int CNT>
+__device__ __forceinline__ void load_col(const double* __restrict__ base, double (&out)[CNT])
+{
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) out[i] = base[(size_t)i * TILE];
+}
+template <int CNT>
+__device__ __forceinline__ void store_col(double* __restrict__ base, const double (&v)[CNT])
+{
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) base[(size_t)i * TILE] = v[i];
+}
+template <int CNT>
+__device__ __forceinline__ void load_uniform(const double* __restrict__ base, double (&out)[CNT])
+{
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) out[i] = base[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_rollout: ilqr.py:30-47 with compute_cost (:49-62) fused.  One lane per problem, one wave per tile.
+// ------------------------------------------------------------------------------------------------
+template <class S>
+__global__ void __launch_bounds__(64) k_rollout(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m, np = S::np;
+    const long long tile = blockIdx.x;
+    const int lane = threadIdx.x;
+    const long long b = tile * TILE + lane;
+    double x[n], p[np], target[n], Rk[m * m], QT[n * n];
+    load_col<n>(a.INIT + (size_t)tile * n * TILE + lane, x);
+    load_col<np>(a.PARAMS + (size_t)tile * np * TILE + lane, p);
+    load_col<n>(a.TARGET + (size_t)tile * n * TILE + lane, target);
+    load_uniform<m * m>(a.WTS + n * n, Rk);
+    load_uniform<n * n>(a.WTS + n * n + m * m, QT);
+    double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
+    const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+    {
+        double x0[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) x0[i] = a.zero_first ? 0.0 : x[i];
+        store_col<n>(Xp, x0);
+    }
+    double cost = 0.0;
+    for (int t = 0; t < a.N; ++t) {
+        double u[m], xn[n];
+        load_col<m>(Up + (size_t)t * m * TILE, u);
+        cost = cost + input_cost<m>(u, Rk);
+        S::f(x, u, a.dt, p, xn);
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = xn[i];
+        store_col<n>(Xp + (size_t)(t + 1) * n * TILE, x);
+    }
+    cost = cost + terminal_cost<n>(x, target, QT);
+    a.cost[b] = cost;
+}
+
+// k_cost: compute_cost (ilqr.py:49-62) of the stored trajectory.
+template <class S>
+__global__ void __launch_bounds__(64) k_cost(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m;
+    const long long tile = blockIdx.x;
+    const int lane = threadIdx.x;
+    double x[n], target[n], Rk[m * m], QT[n * n];
+    load_col<n>(a.TARGET + (size_t)tile * n * TILE + lane, target);
+    load_uniform<m * m>(a.WTS + n * n, Rk);
+    load_uniform<n * n>(a.WTS + n * n + m * m, QT);
+    const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+    double cost = 0.0;
+    for (int t = 0; t < a.N; ++t) {
+        double u[m];
+        load_col<m>(Up + (size_t)t * m * TILE, u);
+        cost = cost + input_cost<m>(u, Rk);
+    }
+    load_col<n>(a.X + ((size_t)tile * a.state_rows + a.N) * n * TILE + lane, x);
+    cost = cost + terminal_cost<n>(x, target, QT);
+    a.cost[tile * TILE + lane] = cost;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_backward: ilqr.py:64-135.  One lane per problem; V_x, V_xx and the step's Q_* stay in VGPRs.
+// ------------------------------------------------------------------------------------------------
+template <class S>
+__global__ void __launch_bounds__(64) k_backward(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m, np = S::np;
+    const long long tile = blockIdx.x;
+    const int lane = threadIdx.x;
+    const long long b = tile * TILE + lane;
+    const bool act = a.active[b] != 0;
+    if (__ballot(act) == 0ull) return;   // whole tile finished
+    double p[np], target[n], Qk[n * n], Rk[m * m], Vx[n], Vxx[n * n];
+    load_col<np>(a.PARAMS + (size_t)tile * np * TILE + lane, p);
+    load_col<n>(a.TARGET + (size_t)tile * n * TILE + lane, target);
+    load_uniform<n * n>(a.WTS, Qk);
+    load_uniform<m * m>(a.WTS + n * n, Rk);
+    load_uniform<n * n>(a.WTS + n * n + m * m, Vxx);                                   // :67  V_xx = Q_T
+    const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
+    const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+    double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + lane;
+    double* kp = a.KFF + (size_t)tile * a.N * m * TILE + lane;
+    {
+        double xN[n], ed[n];
+        load_col<n>(Xp + (size_t)a.N * n * TILE, xN);
+#pragma unroll
+        for (int i = 0; i < n; ++i) ed[i] = xN[i] - target[i];                         // :68
+#pragma unroll
+        for (int i = 0; i < n; ++i) {                                                  // :70  V_x = Q_T @ ed
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < n; ++c) s = __builtin_fma(Vxx[i * n + c], ed[c], s);
+            Vx[i] = s;
+        }
+    }
+    double ecr = 0.0, ecr_g = 0.0, ecr_h = 0.0;
+    bool ok = true;
+    double x[n], u[m];
+    load_col<n>(Xp + (size_t)(a.N - 1) * n * TILE, x);
+    load_col<m>(Up + (size_t)(a.N - 1) * m * TILE, u);
+    for (int t = a.N - 1; t >= 0; --t) {                                               // :82
+        double xnext[n], unext[m];                                                     // prefetch step t-1
+        const int tp = t > 0 ? t - 1 : 0;
+        load_col<n>(Xp + (size_t)tp * n * TILE, xnext);
+        load_col<m>(Up + (size_t)tp * m * TILE, unext);
+        double A[n * n], Bm[n * m], k[m], K[m * n], g, h;
+        S::A(x, u, a.dt, p, A);                                                        // :96
+        S::B(x, u, a.dt, p, Bm);                                                       // :97
+        ok = Riccati<S>::step(A, Bm, u, Qk, Rk, a.quu_reg, Vx, Vxx, k, K, g, h) && ok;
+        if (act) {
+            store_col<m>(kp + (size_t)t * m * TILE, k);                                // :111
+            store_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K);                      // :112
+        }
+        const double cur = g + h;                                                      // :117
+        ecr_g += g; ecr_h += h; ecr += cur;                                            // :119-121
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = xnext[i];
+#pragma unroll
+        for (int j = 0; j < m; ++j) u[j] = unext[j];
+    }
+    if (act) {
+        double* dj = a.dJ + (size_t)tile * 3 * TILE + lane;
+        dj[0] = ecr; dj[TILE] = ecr_g; dj[2 * TILE] = ecr_h;                          // :128-130
+        a.iters[b] += 1;
+        int still = 1;
+        if (!ok) { a.status[b] = ILQR_STATUS_NUMERICAL; still = 0; }
+        else if (fabs(ecr) < a.low_red) { a.status[b] = ILQR_STATUS_OPTIMAL; still = 0; }   // :175
+        if (!still) a.active[b] = 0;
+        if (a.trace && a.it < a.n_iter) {
+            double* tr = a.trace + ((size_t)tile * a.n_iter + a.it) * 6 * TILE + lane;
+            tr[0 * TILE] = a.cost[b]; tr[1 * TILE] = ecr; tr[2 * TILE] = ecr_g; tr[3 * TILE] = ecr_h;
+            tr[4 * TILE] = -1.0; tr[5 * TILE] = __builtin_nan("");
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// closed-loop rollout of one lane (ilqr.py:144-157), accumulating compute_cost; optionally storing.
+// ------------------------------------------------------------------------------------------------
+template <class S, bool STORE>
+__device__ __forceinline__ double closed_loop(const KArgs& a, const double* Xp, const double* Up, const double* Kp,
+                                              const double* kp,
+                                              double* XOp, double* UOp, double (&x)[S::n], const double (&p)[S::np],
+                                              const double (&target)[S::n], const double (&Rk)[S::m * S::m],
+                                              const double (&QT)[S::n * S::n], const double alpha)
+{
+    constexpr int n = S::n, m = S::m;
+    double cost = 0.0;
+    double xb[n], ub[m], K[m * n], kf[m];
+    load_col<n>(Xp, xb); load_col<m>(Up, ub); load_col<m * n>(Kp, K); load_col<m>(kp, kf);
+    for (int t = 0; t < a.N; ++t) {
+        double xb2[n], ub2[m], K2[m * n], kf2[m];                                      // prefetch step t+1 (also makes
+        const int tn = t + 1 < a.N ? t + 1 : t;                                        // the in-place accept safe: the old
+        load_col<n>(Xp + (size_t)tn * n * TILE, xb2);                                  // row t+1 is read before it is
+        load_col<m>(Up + (size_t)tn * m * TILE, ub2);                                  // overwritten below)
+        load_col<m * n>(Kp + (size_t)tn * (m * n) * TILE, K2);
+        load_col<m>(kp + (size_t)tn * m * TILE, kf2);
+        double u[m], xn[n];
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+            const double ff = alpha * kf[j];                                           // :146
+            double fb = 0.0;                                                           // :147
+#pragma unroll
+            for (int i = 0; i < n; ++i) fb = __builtin_fma(K[j * n + i], x[i] - xb[i], fb);
+            u[j] = (ub[j] + fb) + ff;                                                  // :148
+        }
+        cost = cost + input_cost<m>(u, Rk);
+        S::f(x, u, a.dt, p, xn);                                                       // :151
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = xn[i];
+        if constexpr (STORE) {
+            store_col<m>(UOp + (size_t)t * m * TILE, u);                               // :154
+            store_col<n>(XOp + (size_t)(t + 1) * n * TILE, x);                         // :153
+        }
+#pragma unroll
+        for (int i = 0; i < n; ++i) xb[i] = xb2[i];
+#pragma unroll
+        for (int j = 0; j < m; ++j) { ub[j] = ub2[j]; kf[j] = kf2[j]; }
+#pragma unroll
+        for (int i = 0; i < m * n; ++i) K[i] = K2[i];
+    }
+    cost = cost + terminal_cost<n>(x, target, QT);
+    return cost;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_linesearch: ilqr.py:180-202.  W adjacent lanes evaluate W consecutive trials alpha_j of one problem
+// (64/W problems per wave); the accepted trial is the FIRST j whose Armijo ratio passes (:193), found with a
+// ballot over the lane group -- not the lowest cost.  Rounds of W trials repeat until accepted or exhausted.
+// ------------------------------------------------------------------------------------------------
+template <class S, int W>
+__global__ void __launch_bounds__(256) k_linesearch(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m, np = S::np;
+    constexpr int G = TILE / W;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / W, al = lane % W;
+    const long long b = wave * G + grp;
+    if (wave * G >= a.Bpad) return;
+    const long long tile = b >> 6;
+    const int pl = (int)(b & 63);
+    const bool act = a.active[b] != 0;
+    if (__ballot(act) == 0ull) return;
+    double x0[n], p[np], target[n], Rk[m * m], QT[n * n];
+    load_col<n>(a.INIT + (size_t)tile * n * TILE + pl, x0);
+    load_col<np>(a.PARAMS + (size_t)tile * np * TILE + pl, p);
+    load_col<n>(a.TARGET + (size_t)tile * n * TILE + pl, target);
+    load_uniform<m * m>(a.WTS + n * n, Rk);
+    load_uniform<n * n>(a.WTS + n * n + m * m, QT);
+    const double cur_cost = a.cost[b];
+    const double dg = a.dJ[((size_t)tile * 3 + 1) * TILE + pl], dh = a.dJ[((size_t)tile * 3 + 2) * TILE + pl];
+    const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + pl;
+    const double* Up = a.U + (size_t)tile * a.N * m * TILE + pl;
+    const double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + pl;
+    const double* kp = a.KFF + (size_t)tile * a.N * m * TILE + pl;
+    bool done = !act;
+    int accj = -1, rounds = 0;
+    double ncost = __builtin_nan("");
+    for (int r = 0; r * W < a.n_trials; ++r) {
+        const int j = r * W + al;
+        const bool valid = !done && j < a.n_trials;
+        if (__ballot(valid) == 0ull) break;
+        double c = __builtin_nan("");
+        bool okj = false;
+        if (valid) {
+            const double alpha = a.alphas[j];
+            double x[n];
+#pragma unroll
+            for (int i = 0; i < n; ++i) x[i] = x0[i];
+            c = closed_loop<S, false>(a, Xp, Up, Kp, kp, nullptr, nullptr, x, p, target, Rk, QT, alpha);
+            const double cost_difference = cur_cost - c;                               // :191
+            const double expected = alpha * dg + (alpha * alpha) * dh;                 // :192
+            okj = (cost_difference / expected) > a.armijo_thr;                         // :193 (NaN -> false)
+        }
+        if (!done) ++rounds;
+        const unsigned long long mask = __ballot(okj);
+        const unsigned long long gm = (W == 64) ? mask : ((mask >> (grp * W)) & ((1ull << (W % 64)) - 1ull));
+        const int first = gm != 0ull ? __ffsll((long long)gm) - 1 : 0;
+        const double cwin = __shfl(c, grp * W + first);
+        if (!done && gm != 0ull) { accj = r * W + first; ncost = cwin; done = true; }
+    }
+    if (al == 0 && act) {
+        a.acc_j[b] = accj;
+        a.new_cost[b] = ncost;
+        a.ls_rounds[b] += rounds;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_forward: ilqr.forwards_pass (ilqr.py:137-158), one lane per problem.
+//   ACCEPT = true : the accept step of solve (:194-207): problems with acc_j >= 0 re-roll the winning alpha
+//                   in place into X/U, take new_cost as their cost; the others stop with "low learning rate".
+//   ACCEPT = false: plain forwards_pass with a per-problem alpha into XO/UO (+ its cost into new_cost).
+// ------------------------------------------------------------------------------------------------
+template <class S, bool ACCEPT>
+__global__ void __launch_bounds__(64) k_forward(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m, np = S::np;
+    const long long tile = blockIdx.x;
+    const int lane = threadIdx.x;
+    const long long b = tile * TILE + lane;
+    bool run = true;
+    double alpha;
+    int accj = -1;
+    if constexpr (ACCEPT) {
+        const bool act = a.active[b] != 0;
+        accj = act ? a.acc_j[b] : -1;
+        run = act && accj >= 0;
+        alpha = a.alphas[accj >= 0 ? accj : 0];
+        if (act && accj < 0) { a.status[b] = ILQR_STATUS_LOW_LR; a.active[b] = 0; }    // :204-207
+        if (__ballot(run) == 0ull) return;
+    } else {
+        alpha = a.alpha_pp[b];
+    }
+    double x[n], p[np], target[n], Rk[m * m], QT[n * n];
+    load_col<n>(a.INIT + (size_t)tile * n * TILE + lane, x);
+    load_col<np>(a.PARAMS + (size_t)tile * np * TILE + lane, p);
+    load_col<n>(a.TARGET + (size_t)tile * n * TILE + lane, target);
+    load_uniform<m * m>(a.WTS + n * n, Rk);
+    load_uniform<n * n>(a.WTS + n * n + m * m, QT);
+    const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
+    const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+    const double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + lane;
+    const double* kp = a.KFF + (size_t)tile * a.N * m * TILE + lane;
+    double* XOp = a.XO + (size_t)tile * a.state_rows * n * TILE + lane;
+    double* UOp = a.UO + (size_t)tile * a.N * m * TILE + lane;
+    if (run) {
+        if constexpr (!ACCEPT) {
+            double x0[n];
+#pragma unroll
+            for (int i = 0; i < n; ++i) x0[i] = a.zero_first ? 0.0 : x[i];             // :138,:143 (row 0 stays zero)
+            store_col<n>(XOp, x0);
+        }
+        const double c = closed_loop<S, true>(a, Xp, Up, Kp, kp, XOp, UOp, x, p, target, Rk, QT, alpha);
+        if constexpr (ACCEPT) {
+            const double nc = a.new_cost[b];          // cost of the winning trial as the line search saw it
+            a.cost[b] = nc;                                                            // :197
+            a.accepts[b] += 1;
+            if (a.trace && a.it < a.n_iter) {
+                double* tr = a.trace + ((size_t)tile * a.n_iter + a.it) * 6 * TILE + lane;
+                tr[4 * TILE] = (double)accj; tr[5 * TILE] = nc;
+            }
+            (void)c;
+        } else {
+            a.new_cost[b] = c;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_ltvlqr: ltvlqr.py:3-28.  One lane per problem; P stays in VGPRs.
+// K = -inv(R + B'PB) B'PA,  P <- Q + A'PA - (A'PB) inv(R + B'PB) (B'PA)
+// ------------------------------------------------------------------------------------------------
+template <class S>
+__global__ void __launch_bounds__(64) k_ltvlqr(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m, np = S::np;
+    const long long tile = blockIdx.x;
+    const int lane = threadIdx.x;
+    double p[np], Qk[n * n], Rk[m * m], P[n * n];
+    load_col<np>(a.PARAMS + (size_t)tile * np * TILE + lane, p);
+    load_uniform<n * n>(a.WTS, Qk);
+    load_uniform<m * m>(a.WTS + n * n, Rk);
+    load_uniform<n * n>(a.WTS + n * n + m * m, P);                                     // :14
+    const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
+    const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+    double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + lane;
+    bool ok = true;
+    double x[n], u[m];
+    load_col<n>(Xp + (size_t)(a.N - 1) * n * TILE, x);
+    load_col<m>(Up + (size_t)(a.N - 1) * m * TILE, u);
+    for (int t = a.N - 1; t >= 0; --t) {                                               // :15
+        double xnext[n], unext[m];
+        const int tp = t > 0 ? t - 1 : 0;
+        load_col<n>(Xp + (size_t)tp * n * TILE, xnext);
+        load_col<m>(Up + (size_t)tp * m * TILE, unext);
+        double A[n * n], Bm[n * m];
+        S::A(x, u, a.dt, p, A);                                                        // :21
+        S::B(x, u, a.dt, p, Bm);                                                       // :22
+        double BtP[m * n], BtPA[m * n], G[m * m], Gi[m * m], K[m * n];
+#pragma unroll
+        for (int j = 0; j < m; ++j)
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::b_kind(r * m + j), Bm[r * m + j], P[r * n + c]);
+                BtP[j * n + c] = s;
+            }
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::a_kind(r * n + c), A[r * n + c], BtP[j * n + r]);
+                BtPA[j * n + c] = s;
+            }
+#pragma unroll
+            for (int l = 0; l < m; ++l) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::b_kind(r * m + l), Bm[r * m + l], BtP[j * n + r]);
+                G[j * m + l] = Rk[j * m + l] + s;
+            }
+        }
+        ok = Riccati<S>::inv_spd(G, Gi) && ok;
+#pragma unroll
+        for (int j = 0; j < m; ++j)
+#pragma unroll
+            for (int c = 0; c < n; ++c) {                                              // :24
+                double s = 0.0;
+#pragma unroll
+                for (int l = 0; l < m; ++l) s = __builtin_fma(-Gi[j * m + l], BtPA[l * n + c], s);
+                K[j * n + c] = s;
+            }
+        store_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K);                          // :25
+        // :27  P = Q + A'PA - (A'PB) Gi (B'PA);  (A'PB)[i][l] is formed from the rows of A'P
+        double Pn[n * n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double row[n], apb[m];
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::a_kind(r * n + i), A[r * n + i], P[r * n + c]);
+                row[c] = s;
+            }
+#pragma unroll
+            for (int l = 0; l < m; ++l) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::b_kind(r * m + l), Bm[r * m + l], row[r]);
+                apb[l] = s;
+            }
+            double w[m];                                                               // (A'PB Gi)[i][:]
+#pragma unroll
+            for (int l = 0; l < m; ++l) {
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < m; ++q) s = __builtin_fma(apb[q], Gi[q * m + l], s);
+                w[l] = s;
+            }
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::a_kind(r * n + c), A[r * n + c], row[r]);
+                double corr = 0.0;
+#pragma unroll
+                for (int l = 0; l < m; ++l) corr = __builtin_fma(w[l], BtPA[l * n + c], corr);
+                Pn[i * n + c] = (Qk[i * n + c] + s) - corr;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < n * n; ++i) P[i] = Pn[i];
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = xnext[i];
+#pragma unroll
+        for (int j = 0; j < m; ++j) u[j] = unext[j];
+    }
+    if (!ok) a.status[tile * TILE + lane] = ILQR_STATUS_NUMERICAL;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_dynamics: the lambdified callables evaluated at `count` points (array-of-structs in and out)
+// ------------------------------------------------------------------------------------------------
+template <class S>
+__global__ void __launch_bounds__(64) k_dynamics(int which, long long count, const double* __restrict__ xs,
+                                                 const double* __restrict__ us, double dt, const double* __restrict__ ps,
+                                                 double* __restrict__ out)
+{
+    constexpr int n = S::n, m = S::m, np = S::np;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double x[n], u[m], p[np];
+#pragma unroll
+    for (int q = 0; q < n; ++q) x[q] = xs[i * n + q];
+#pragma unroll
+    for (int q = 0; q < m; ++q) u[q] = us[i * m + q];
+#pragma unroll
+    for (int q = 0; q < np; ++q) p[q] = ps[q];
+    if (which == 0) {
+        double o[n];
+        S::f(x, u, dt, p, o);
+#pragma unroll
+        for (int q = 0; q < n; ++q) out[i * n + q] = o[q];
+    } else if (which == 1) {
+        double o[n * n];
+        S::A(x, u, dt, p, o);
+#pragma unroll
+        for (int q = 0; q < n * n; ++q) out[i * n * n + q] = o[q];
+    } else {
+        double o[n * m];
+        S::B(x, u, dt, p, o);
+#pragma unroll
+        for (int q = 0; q < n * m; ++q) out[i * n * m + q] = o[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout conversion.  ref: (B, T, C) with problem stride bstride (0 = one shared problem), tiled:
+// [tile][T][C][64].  Padding problems (b >= B) replicate problem B-1 so every lane computes on valid data.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_pack(const T* __restrict__ ref, T* __restrict__ tiled, long long B, long long Bpad,
+                                              long long TCcopy, long long TCdst, long long bstride)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Bpad * TCcopy) return;
+    const int lane = (int)(idx & 63);
+    const long long rest = idx >> 6;
+    const long long tc = rest % TCcopy, tile = rest / TCcopy;
+    long long b = tile * TILE + lane;
+    if (b >= B) b = B - 1;
+    tiled[(tile * TCdst + tc) * TILE + lane] = ref[b * bstride + tc];
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_unpack(const T* __restrict__ tiled, T* __restrict__ ref, long long B, long long Bpad,
+                                                long long TC)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Bpad * TC) return;
+    const int lane = (int)(idx & 63);
+    const long long rest = idx >> 6;
+    const long long tc = rest % TC, tile = rest / TC;
+    const long long b = tile * TILE + lane;
+    if (b < B) ref[b * TC + tc] = tiled[idx];
+}
+__global__ void __launch_bounds__(256) k_fill_i32(int* p, long long cnt, int v)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) p[i] = v;
+}
+__global__ void __launch_bounds__(256) k_fill_f64(double* p, long long cnt, double v)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(-100 - (int)e_, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+enum { KID_ROLLOUT = 0, KID_BACKWARD = 1, KID_LINESEARCH = 2, KID_ACCEPT = 3, KID_LTVLQR = 4, KID_FORWARD = 5, KID_COST = 6 };
+
+}  // namespace
+
+struct ilqr_ws {
+    ilqr_desc d;
+    int n, m, np, N, W, n_trials, want_trace;
+    long long B, Bpad, tiles;
+    hipStream_t stream;
+    double *X, *U, *KFB, *KFF, *XO, *UO, *INIT, *TARGET, *PARAMS, *WTS, *alphas, *alpha_pp, *cost, *new_cost, *dJ, *trace;
+    int *active, *iters, *status, *acc_j, *ls_rounds, *accepts;
+    void* staging;
+    size_t staging_bytes;
+    size_t hbm_bytes;
+    int state_rows;
+    bool profiling;
+    struct Ev { hipEvent_t a, b; int kid; };
+    std::vector<Ev> events;
+    double prof_ms[N_KERNEL_IDS];
+    long long prof_cnt[N_KERNEL_IDS];
+};
+
+namespace {
+
+KArgs make_args(ilqr_ws* ws, int it)
+{
+    KArgs a;
+    memset(&a, 0, sizeof(a));
+    a.N = ws->N; a.it = it; a.n_iter = ws->d.n_iterations; a.zero_first = ws->d.zero_first_state;
+    a.n_trials = ws->n_trials; a.state_rows = ws->state_rows; a.n_tiles = ws->tiles;
+    a.dt = ws->d.dt; a.low_red = ws->d.low_expected_reduction; a.armijo_thr = ws->d.armijo_threshold;
+    a.quu_reg = ws->d.quu_reg;
+    a.X = ws->X; a.U = ws->U; a.KFB = ws->KFB; a.KFF = ws->KFF; a.XO = ws->X; a.UO = ws->U;
+    a.INIT = ws->INIT; a.TARGET = ws->TARGET; a.PARAMS = ws->PARAMS; a.WTS = ws->WTS; a.alphas = ws->alphas;
+    a.alpha_pp = ws->alpha_pp; a.cost = ws->cost; a.new_cost = ws->new_cost; a.dJ = ws->dJ; a.active = ws->active;
+    a.iters = ws->iters; a.status = ws->status; a.acc_j = ws->acc_j; a.ls_rounds = ws->ls_rounds;
+    a.accepts = ws->accepts; a.trace = ws->want_trace ? ws->trace : nullptr; a.Bpad = ws->Bpad;
+    return a;
+}
+
+template <class F>
+int with_system(int sys, F&& fn)
+{
+    switch (sys) {
+        case 0: return fn(Sys_pendulum{});
+        case 1: return fn(Sys_acrobot{});
+        case 2: return fn(Sys_cartpole{});
+        case 3: return fn(Sys_quadcopter{});
+    }
+    return fail(-2, "unknown system id %d", sys);
+}
+
+struct ProfScope {
+    ilqr_ws* ws; int kid; hipEvent_t a, b; bool on;
+    ProfScope(ilqr_ws* w, int k) : ws(w), kid(k), a(nullptr), b(nullptr), on(w->profiling)
+    {
+        if (on) {
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            (void)hipEventRecord(a, ws->stream);
+        }
+    }
+    ~ProfScope()
+    {
+        if (on) {
+            (void)hipEventRecord(b, ws->stream);
+            ws->events.push_back({a, b, kid});
+        }
+    }
+};
+
+int check_launch(const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-100 - (int)e, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+template <class S, int W>
+void launch_ls(ilqr_ws* ws, const KArgs& a)
+{
+    const long long waves = ws->Bpad * W / TILE;
+    const int wpb = 4;   // 256 threads
+    const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
+    hipLaunchKernelGGL((k_linesearch<S, W>), dim3(grid), dim3(256), 0, ws->stream, a);
+}
+
+int set_device(const ilqr_ws* ws)
+{
+    HIPCHK(hipSetDevice(ws->d.device));
+    return 0;
+}
+
+size_t field_elems(const ilqr_ws* ws, int field, int* is_int, long long* tc_out, double** dptr, int** iptr)
+{
+    const long long N = ws->N, n = ws->n, m = ws->m, np = ws->np;
+    *is_int = 0; *dptr = nullptr; *iptr = nullptr;
+    long long tc = 0;
+    switch (field) {
+        case ILQR_F_INIT: tc = n; *dptr = ws->INIT; break;
+        case ILQR_F_TARGET: tc = n; *dptr = ws->TARGET; break;
+        case ILQR_F_PARAMS: tc = np; *dptr = ws->PARAMS; break;
+        case ILQR_F_STATES: tc = (long long)ws->state_rows * n; *dptr = ws->X; break;
+        case ILQR_F_INPUTS: tc = N * m; *dptr = ws->U; break;
+        case ILQR_F_KFF: tc = N * m; *dptr = ws->KFF; break;
+        case ILQR_F_KFB: tc = N * m * n; *dptr = ws->KFB; break;
+        case ILQR_F_COST: tc = 1; *dptr = ws->cost; break;
+        case ILQR_F_NEW_COST: tc = 1; *dptr = ws->new_cost; break;
+        case ILQR_F_ALPHA: tc = 1; *dptr = ws->alpha_pp; break;
+        case ILQR_F_DJ: tc = 3; *dptr = ws->dJ; break;
+        case ILQR_F_ITERS: tc = 1; *is_int = 1; *iptr = ws->iters; break;
+        case ILQR_F_STATUS: tc = 1; *is_int = 1; *iptr = ws->status; break;
+        case ILQR_F_LS_ROUNDS: tc = 1; *is_int = 1; *iptr = ws->ls_rounds; break;
+        case ILQR_F_ACCEPTS: tc = 1; *is_int = 1; *iptr = ws->accepts; break;
+        case ILQR_F_TRACE: tc = (long long)ws->d.n_iterations * 6; *dptr = ws->trace; break;
+        case ILQR_F_STATES_OUT: tc = (long long)ws->state_rows * n; *dptr = ws->XO; break;
+        case ILQR_F_INPUTS_OUT: tc = N * m; *dptr = ws->UO; break;
+        default: return 0;
+    }
+    *tc_out = tc;
+    return (size_t)tc;
+}
+
+int ensure_staging(ilqr_ws* ws, size_t bytes)
+{
+    if (ws->staging_bytes >= bytes) return 0;
+    if (ws->staging) { HIPCHK(hipFree(ws->staging)); ws->staging = nullptr; ws->staging_bytes = 0; }
+    HIPCHK(hipMalloc(&ws->staging, bytes));
+    ws->staging_bytes = bytes;
+    return 0;
+}
+
+int ensure_forward_out(ilqr_ws* ws)
+{
+    if (ws->XO) return 0;
+    const size_t xs = (size_t)ws->Bpad * ws->state_rows * ws->n * sizeof(double);
+    const size_t us = (size_t)ws->Bpad * ws->N * ws->m * sizeof(double);
+    HIPCHK(hipMalloc((void**)&ws->XO, xs));
+    HIPCHK(hipMalloc((void**)&ws->UO, us));
+    ws->hbm_bytes += xs + us;
+    return 0;
+}
+
+// every per-problem array is [tile][TC][64] on the device and (B,TC) at the boundary
+int do_upload(ilqr_ws* ws, int field, const void* src, bool src_on_device, long long rows)
+{
+    int rc = set_device(ws);
+    if (rc) return rc;
+    if (field == ILQR_F_STATES_OUT || field == ILQR_F_INPUTS_OUT) { rc = ensure_forward_out(ws); if (rc) return rc; }
+    int is_int; long long tc; double* dp; int* ip;
+    if (!field_elems(ws, field, &is_int, &tc, &dp, &ip)) return fail(-3, "upload: unknown field %d", field);
+    if (is_int || field == ILQR_F_DJ || field == ILQR_F_TRACE) return fail(-3, "upload: field %d is output only", field);
+    if (!dp) return fail(-3, "upload: field %d not allocated", field);
+    long long bstride = tc, copy_elems;
+    long long tc_eff = tc;
+    if (field == ILQR_F_TARGET && !ws->d.target_batched) bstride = 0;
+    if (field == ILQR_F_PARAMS && !ws->d.params_batched) bstride = 0;
+    if (field == ILQR_F_STATES) {
+        const long long r = rows > 0 ? rows : ws->state_rows;
+        if (r < ws->N) return fail(-3, "upload: states needs at least N=%d rows per problem, got %lld", ws->N, r);
+        // only min(r, state_rows) rows are packed; the source stride is r rows
+        bstride = r * ws->n;
+        if (r < ws->state_rows) tc_eff = r * ws->n;
+    }
+    copy_elems = bstride == 0 ? tc : bstride * ws->B;
+    const double* dsrc = (const double*)src;
+    if (!src_on_device) {
+        rc = ensure_staging(ws, (size_t)copy_elems * sizeof(double));
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(ws->staging, src, (size_t)copy_elems * sizeof(double), hipMemcpyHostToDevice, ws->stream));
+        dsrc = (const double*)ws->staging;
+    }
+    {
+        // tc_eff < tc only for states given with exactly N rows (ltvlqr): the last row of the buffer stays untouched
+        const long long total = ws->Bpad * tc_eff;
+        hipLaunchKernelGGL(k_pack<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ws->stream, dsrc, dp, ws->B,
+                           ws->Bpad, tc_eff, tc, bstride);
+    }
+    rc = check_launch("k_pack");
+    if (rc) return rc;
+    if (!src_on_device) HIPCHK(hipStreamSynchronize(ws->stream));   // staging is reused by the next upload
+    return 0;
+}
+
+int do_download(ilqr_ws* ws, int field, void* dst, bool dst_on_device)
+{
+    int rc = set_device(ws);
+    if (rc) return rc;
+    int is_int; long long tc; double* dp; int* ip;
+    if (!field_elems(ws, field, &is_int, &tc, &dp, &ip)) return fail(-3, "download: unknown field %d", field);
+    if (field == ILQR_F_TRACE && !ws->want_trace) return fail(-3, "download: workspace was created without a trace");
+    if (!dp && !ip) return fail(-3, "download: field %d not allocated", field);
+    const size_t esz = is_int ? sizeof(int) : sizeof(double);
+    const size_t bytes = (size_t)ws->B * tc * esz;
+    void* ddst = dst;
+    if (!dst_on_device) {
+        rc = ensure_staging(ws, bytes);
+        if (rc) return rc;
+        ddst = ws->staging;
+    }
+    const long long total = ws->Bpad * tc;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (is_int) {
+        hipLaunchKernelGGL(k_unpack<int>, dim3(grid), dim3(256), 0, ws->stream, ip, (int*)ddst, ws->B, ws->Bpad, tc);
+    } else {
+        hipLaunchKernelGGL(k_unpack<double>, dim3(grid), dim3(256), 0, ws->stream, dp, (double*)ddst, ws->B, ws->Bpad, tc);
+    }
+    rc = check_launch("k_unpack");
+    if (rc) return rc;
+    if (!dst_on_device) {
+        HIPCHK(hipMemcpyAsync(dst, ws->staging, bytes, hipMemcpyDeviceToHost, ws->stream));
+        HIPCHK(hipStreamSynchronize(ws->stream));
+    }
+    return 0;
+}
+
+int fill_i32(ilqr_ws* ws, int* p, int v)
+{
+    hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((ws->Bpad + 255) / 256)), dim3(256), 0, ws->stream, p, ws->Bpad, v);
+    return check_launch("k_fill_i32");
+}
+
+template <class F>
+int run_pass(ilqr_ws* ws, int kid, int it, const char* name, F&& launch)
+{
+    if (!ws) return fail(-1, "null workspace");
+    int rc = set_device(ws);
+    if (rc) return rc;
+    const KArgs a = make_args(ws, it);
+    ProfScope ps(ws, kid);
+    return with_system(ws->d.system_id, [&](auto S) {
+        launch(S, a);
+        return check_launch(name);
+    });
+}
+
+int validate_desc(const ilqr_desc* d)
+{
+    if (!d) return fail(-1, "null descriptor");
+    if (d->system_id < 0 || d->system_id > 3) return fail(-2, "unknown system id %d", d->system_id);
+    if (d->batch < 1) return fail(-1, "batch must be >= 1 (got %lld)", (long long)d->batch);
+    if (d->n_timesteps < 1) return fail(-1, "n_timesteps must be >= 1 (got %d)", d->n_timesteps);
+    if (d->n_iterations < 0) return fail(-1, "n_iterations must be >= 0");
+    const int w = d->n_alpha_parallel;
+    if (w != 0 && (w < 1 || w > 64 || (w & (w - 1)) != 0)) return fail(-1, "n_alpha_parallel must be 0 or a power of two <= 64");
+    if (!(d->learning_speed > 0.0 && d->learning_speed < 1.0)) return fail(-1, "learning_speed must be in (0,1)");
+    if (!(d->low_learning_rate > 0.0 && d->low_learning_rate < 1.0)) return fail(-1, "low_learning_rate must be in (0,1)");
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+void ilqr_desc_default(ilqr_desc* d)
+{
+    memset(d, 0, sizeof(*d));
+    d->batch = 1;
+    d->n_alpha_parallel = 0;
+    d->zero_first_state = 1;
+    d->learning_speed = 0.95;
+    d->low_learning_rate = 0.05;
+    d->low_expected_reduction = 1e-3;
+    d->armijo_threshold = 0.1;
+    d->quu_reg = 0.0;
+}
+
+int ilqr_abi_version(void) { return ILQR_ABI_VERSION; }
+
+int ilqr_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+const char* ilqr_last_error(void) { return g_err; }
+
+int ilqr_system_dims(int32_t sys, int32_t* n, int32_t* m, int32_t* np)
+{
+    if (sys < 0 || sys > 3) return fail(-2, "unknown system id %d", sys);
+    if (n) *n = SYSTEMS[sys].n;
+    if (m) *m = SYSTEMS[sys].m;
+    if (np) *np = SYSTEMS[sys].np;
+    return 0;
+}
+
+int ilqr_system_lookup(const char* name, int32_t* n, int32_t* m, int32_t* np)
+{
+    if (!name) return fail(-2, "null system name");
+    for (int i = 0; i < 4; ++i)
+        if (strcmp(name, SYSTEMS[i].name) == 0) {
+            ilqr_system_dims(i, n, m, np);
+            return i;
+        }
+    return fail(-2, "unknown system '%s' (compiled in: pendulum, acrobot, cartpole, quadcopter)", name);
+}
+
+int ilqr_dynamics_eval(int32_t sys, int32_t which, int64_t count, const double* x, const double* u, double dt,
+                       const double* params, double* out, int32_t device)
+{
+    if (sys < 0 || sys > 3) return fail(-2, "unknown system id %d", sys);
+    if (which < 0 || which > 2) return fail(-1, "which must be 0 (f), 1 (A) or 2 (B)");
+    if (count < 0) return fail(-1, "negative count");
+    if (count == 0) return 0;
+    HIPCHK(hipSetDevice(device));
+    const int n = SYSTEMS[sys].n, m = SYSTEMS[sys].m, np = SYSTEMS[sys].np;
+    const size_t osz = which == 0 ? n : (which == 1 ? n * n : n * m);
+    double *dx = nullptr, *du = nullptr, *dp = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc((void**)&dx, count * n * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&du, count * m * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&dp, np * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&dout, count * osz * sizeof(double)));
+    HIPCHK(hipMemcpy(dx, x, count * n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(du, u, count * m * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dp, params, np * sizeof(double), hipMemcpyHostToDevice));
+    const unsigned grid = (unsigned)((count + 63) / 64);
+    int rc = with_system(sys, [&](auto S) {
+        using T = decltype(S);
+        hipLaunchKernelGGL(k_dynamics<T>, dim3(grid), dim3(64), 0, 0, which, (long long)count, dx, du, dt, dp, dout);
+        return check_launch("k_dynamics");
+    });
+    if (rc == 0) {
+        hipError_t e = hipMemcpy(out, dout, count * osz * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(-100 - (int)e, "hipMemcpy D2H: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(dx); (void)hipFree(du); (void)hipFree(dp); (void)hipFree(dout);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------- workspace
+int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
+{
+    int rc = validate_desc(d);
+    if (rc) return rc;
+    if (!out) return fail(-1, "null output pointer");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (d->device < 0 || d->device >= ndev) return fail(-1, "device %d out of range (%d visible)", d->device, ndev);
+    HIPCHK(hipSetDevice(d->device));
+    ilqr_ws* ws = new (std::nothrow) ilqr_ws();
+    if (!ws) return fail(-4, "out of host memory");
+    ws->d = *d;
+    ws->n = SYSTEMS[d->system_id].n; ws->m = SYSTEMS[d->system_id].m; ws->np = SYSTEMS[d->system_id].np;
+    ws->N = d->n_timesteps; ws->B = d->batch;
+    ws->tiles = (ws->B + TILE - 1) / TILE; ws->Bpad = ws->tiles * TILE;
+    ws->state_rows = ws->N + 1;
+    ws->want_trace = want_trace && d->n_iterations > 0;
+    ws->profiling = false;
+    memset(ws->prof_ms, 0, sizeof(ws->prof_ms));
+    memset(ws->prof_cnt, 0, sizeof(ws->prof_cnt));
+    // alpha table by repeated multiplication (ilqr.py:180,202) and the number of trials with alpha > low_lr (:185)
+    double alphas[MAX_TRIALS];
+    double lr = 1.0;
+    int n_trials = 0;
+    for (int j = 0; j < MAX_TRIALS; ++j) {
+        alphas[j] = lr;
+        if (lr > d->low_learning_rate && n_trials == j) n_trials = j + 1;
+        lr = d->learning_speed * lr;
+    }
+    if (n_trials == MAX_TRIALS && lr > d->low_learning_rate) {
+        delete ws;
+        return fail(-1, "learning_speed/low_learning_rate need more than %d line-search trials", MAX_TRIALS);
+    }
+    ws->n_trials = n_trials;
+    int W = d->n_alpha_parallel;
+    if (W == 0) {   // auto: enough waves to fill 256 CUs x 4 SIMDs a few times over, at least 8 lanes per problem
+        W = 8;
+        while (W < 64 && ws->Bpad * (long long)(W * 2) / TILE <= 4096) W *= 2;
+    }
+    ws->W = W;
+    const size_t Bp = (size_t)ws->Bpad, n = ws->n, m = ws->m, np = ws->np, N = ws->N;
+    struct { void** p; size_t bytes; } allocs[] = {
+        {(void**)&ws->X, Bp * (N + 1) * n * 8}, {(void**)&ws->U, Bp * N * m * 8}, {(void**)&ws->KFB, Bp * N * m * n * 8},
+        {(void**)&ws->KFF, Bp * N * m * 8}, {(void**)&ws->INIT, Bp * n * 8}, {(void**)&ws->TARGET, Bp * n * 8},
+        {(void**)&ws->PARAMS, Bp * np * 8}, {(void**)&ws->WTS, (2 * n * n + m * m) * 8}, {(void**)&ws->alphas, MAX_TRIALS * 8},
+        {(void**)&ws->alpha_pp, Bp * 8}, {(void**)&ws->cost, Bp * 8}, {(void**)&ws->new_cost, Bp * 8}, {(void**)&ws->dJ, 3 * Bp * 8},
+        {(void**)&ws->active, Bp * 4}, {(void**)&ws->iters, Bp * 4}, {(void**)&ws->status, Bp * 4}, {(void**)&ws->acc_j, Bp * 4},
+        {(void**)&ws->ls_rounds, Bp * 4}, {(void**)&ws->accepts, Bp * 4},
+        {(void**)&ws->trace, ws->want_trace ? Bp * (size_t)d->n_iterations * 6 * 8 : 0},
+    };
+    ws->hbm_bytes = 0;
+    for (auto& al : allocs) {
+        *al.p = nullptr;
+        if (al.bytes == 0) continue;
+        hipError_t e = hipMalloc(al.p, al.bytes);
+        if (e != hipSuccess) {
+            const int code = fail(-100 - (int)e, "hipMalloc of %zu bytes failed: %s", al.bytes, hipGetErrorString(e));
+            ilqr_ws_destroy(ws);
+            return code;
+        }
+        ws->hbm_bytes += al.bytes;
+    }
+    hipError_t e = hipStreamCreate(&ws->stream);
+    if (e != hipSuccess) { ilqr_ws_destroy(ws); return fail(-100 - (int)e, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    HIPCHK(hipMemcpy(ws->alphas, alphas, sizeof(alphas), hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetAsync(ws->WTS, 0, (2 * n * n + m * m) * 8, ws->stream));
+    HIPCHK(hipMemsetAsync(ws->dJ, 0, 3 * Bp * 8, ws->stream));
+    HIPCHK(hipMemsetAsync(ws->KFB, 0, Bp * N * m * n * 8, ws->stream));
+    HIPCHK(hipMemsetAsync(ws->KFF, 0, Bp * N * m * 8, ws->stream));
+    HIPCHK(hipMemsetAsync(ws->X, 0, Bp * (N + 1) * n * 8, ws->stream));
+    HIPCHK(hipMemsetAsync(ws->U, 0, Bp * N * m * 8, ws->stream));
+    HIPCHK(hipMemsetAsync(ws->cost, 0, Bp * 8, ws->stream));
+    HIPCHK(hipMemsetAsync(ws->new_cost, 0, Bp * 8, ws->stream));
+    HIPCHK(hipMemsetAsync(ws->TARGET, 0, Bp * n * 8, ws->stream));
+    *out = ws;
+    rc = ilqr_ws_reset(ws);
+    if (rc) { ilqr_ws_destroy(ws); *out = nullptr; return rc; }
+    HIPCHK(hipStreamSynchronize(ws->stream));
+    return 0;
+}
+
+int ilqr_ws_destroy(ilqr_ws* ws)
+{
+    if (!ws) return 0;
+    (void)hipSetDevice(ws->d.device);
+    if (ws->stream) (void)hipStreamSynchronize(ws->stream);
+    for (auto& ev : ws->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    void* ptrs[] = {ws->X, ws->U, ws->KFB, ws->KFF, ws->XO, ws->UO, ws->INIT, ws->TARGET, ws->PARAMS, ws->WTS, ws->alphas,
+                    ws->alpha_pp, ws->cost, ws->new_cost, ws->dJ, ws->trace, ws->active, ws->iters, ws->status, ws->acc_j,
+                    ws->ls_rounds, ws->accepts, ws->staging};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (ws->stream) (void)hipStreamDestroy(ws->stream);
+    delete ws;
+    return 0;
+}
+
+int ilqr_ws_set_weights(ilqr_ws* ws, const double* Qk, const double* Rk, const double* QT)
+{
+    if (!ws) return fail(-1, "null workspace");
+    int rc = set_device(ws);
+    if (rc) return rc;
+    const size_t n = ws->n, m = ws->m;
+    std::vector<double> w(2 * n * n + m * m, 0.0);
+    if (Qk) memcpy(w.data(), Qk, n * n * 8);
+    if (Rk) memcpy(w.data() + n * n, Rk, m * m * 8);
+    if (QT) memcpy(w.data() + n * n + m * m, QT, n * n * 8);
+    HIPCHK(hipMemcpyAsync(ws->WTS, w.data(), w.size() * 8, hipMemcpyHostToDevice, ws->stream));
+    HIPCHK(hipStreamSynchronize(ws->stream));
+    return 0;
+}
+
+int ilqr_ws_upload(ilqr_ws* ws, int32_t field, const void* src, int64_t rows)
+{
+    if (!ws || !src) return fail(-1, "null argument");
+    return do_upload(ws, field, src, false, rows);
+}
+int ilqr_ws_upload_device(ilqr_ws* ws, int32_t field, const void* src, int64_t rows)
+{
+    if (!ws || !src) return fail(-1, "null argument");
+    return do_upload(ws, field, src, true, rows);
+}
+int ilqr_ws_download(ilqr_ws* ws, int32_t field, void* dst)
+{
+    if (!ws || !dst) return fail(-1, "null argument");
+    return do_download(ws, field, dst, false);
+}
+int ilqr_ws_download_device(ilqr_ws* ws, int32_t field, void* dst)
+{
+    if (!ws || !dst) return fail(-1, "null argument");
+    return do_download(ws, field, dst, true);
+}
+
+int ilqr_ws_reset(ilqr_ws* ws)
+{
+    if (!ws) return fail(-1, "null workspace");
+    int rc = set_device(ws);
+    if (rc) return rc;
+    if ((rc = fill_i32(ws, ws->active, 1))) return rc;
+    if ((rc = fill_i32(ws, ws->iters, 0))) return rc;
+    if ((rc = fill_i32(ws, ws->status, ILQR_STATUS_MAX_ITER))) return rc;
+    if ((rc = fill_i32(ws, ws->acc_j, -1))) return rc;
+    if ((rc = fill_i32(ws, ws->ls_rounds, 0))) return rc;
+    if ((rc = fill_i32(ws, ws->accepts, 0))) return rc;
+    if (ws->want_trace) {
+        const long long cnt = ws->Bpad * (long long)ws->d.n_iterations * 6;
+        hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ws->stream, ws->trace, cnt,
+                           __builtin_nan(""));
+        if ((rc = check_launch("k_fill_f64"))) return rc;
+    }
+    return 0;
+}
+
+int ilqr_ws_rollout(ilqr_ws* ws)
+{
+    return run_pass(ws, KID_ROLLOUT, 0, "k_rollout", [&](auto S, const KArgs& a) {
+        hipLaunchKernelGGL(k_rollout<decltype(S)>, dim3((unsigned)ws->tiles), dim3(64), 0, ws->stream, a);
+    });
+}
+int ilqr_ws_cost(ilqr_ws* ws)
+{
+    return run_pass(ws, KID_COST, 0, "k_cost", [&](auto S, const KArgs& a) {
+        hipLaunchKernelGGL(k_cost<decltype(S)>, dim3((unsigned)ws->tiles), dim3(64), 0, ws->stream, a);
+    });
+}
+int ilqr_ws_backward(ilqr_ws* ws, int32_t iteration)
+{
+    return run_pass(ws, KID_BACKWARD, iteration, "k_backward", [&](auto S, const KArgs& a) {
+        hipLaunchKernelGGL(k_backward<decltype(S)>, dim3((unsigned)ws->tiles), dim3(64), 0, ws->stream, a);
+    });
+}
+int ilqr_ws_linesearch(ilqr_ws* ws)
+{
+    return run_pass(ws, KID_LINESEARCH, 0, "k_linesearch", [&](auto S, const KArgs& a) {
+        using T = decltype(S);
+        switch (ws->W) {
+            case 1: launch_ls<T, 1>(ws, a); break;
+            case 2: launch_ls<T, 2>(ws, a); break;
+            case 4: launch_ls<T, 4>(ws, a); break;
+            case 8: launch_ls<T, 8>(ws, a); break;
+            case 16: launch_ls<T, 16>(ws, a); break;
+            case 32: launch_ls<T, 32>(ws, a); break;
+            default: launch_ls<T, 64>(ws, a); break;
+        }
+    });
+}
+int ilqr_ws_accept(ilqr_ws* ws, int32_t iteration)
+{
+    return run_pass(ws, KID_ACCEPT, iteration, "k_forward<accept>", [&](auto S, const KArgs& a) {
+        hipLaunchKernelGGL((k_forward<decltype(S), true>), dim3((unsigned)ws->tiles), dim3(64), 0, ws->stream, a);
+    });
+}
+int ilqr_ws_forward(ilqr_ws* ws, int32_t with_cost)
+{
+    (void)with_cost;   // the cost of the new trajectory is always produced (NEW_COST)
+    if (!ws) return fail(-1, "null workspace");
+    int rc = set_device(ws);
+    if (rc) return rc;
+    if ((rc = ensure_forward_out(ws))) return rc;
+    return run_pass(ws, KID_FORWARD, 0, "k_forward", [&](auto S, const KArgs& a0) {
+        KArgs a = a0;
+        a.XO = ws->XO; a.UO = ws->UO;
+        hipLaunchKernelGGL((k_forward<decltype(S), false>), dim3((unsigned)ws->tiles), dim3(64), 0, ws->stream, a);
+    });
+}
+int ilqr_ws_ltvlqr(ilqr_ws* ws)
+{
+    return run_pass(ws, KID_LTVLQR, 0, "k_ltvlqr", [&](auto S, const KArgs& a) {
+        hipLaunchKernelGGL(k_ltvlqr<decltype(S)>, dim3((unsigned)ws->tiles), dim3(64), 0, ws->stream, a);
+    });
+}
+
+int ilqr_ws_solve(ilqr_ws* ws)
+{
+    int rc;
+    if ((rc = ilqr_ws_reset(ws))) return rc;
+    if ((rc = ilqr_ws_rollout(ws))) return rc;                 // ilqr.py:162-164
+    for (int it = 0; it < ws->d.n_iterations; ++it) {          // :170
+        if ((rc = ilqr_ws_backward(ws, it))) return rc;        // :173-179
+        if ((rc = ilqr_ws_linesearch(ws))) return rc;          // :180-202
+        if ((rc = ilqr_ws_accept(ws, it))) return rc;          // :194-207
+    }
+    return 0;
+}
+
+int ilqr_ws_sync(ilqr_ws* ws)
+{
+    if (!ws) return fail(-1, "null workspace");
+    int rc = set_device(ws);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ws->stream));
+    return 0;
+}
+
+int ilqr_ws_profile(ilqr_ws* ws, int32_t enable)
+{
+    if (!ws) return fail(-1, "null workspace");
+    for (auto& ev : ws->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    ws->events.clear();
+    memset(ws->prof_ms, 0, sizeof(ws->prof_ms));
+    memset(ws->prof_cnt, 0, sizeof(ws->prof_cnt));
+    ws->profiling = enable != 0;
+    return 0;
+}
+
+int ilqr_ws_profile_read(ilqr_ws* ws, double* ms, int64_t* launches)
+{
+    if (!ws) return fail(-1, "null workspace");
+    int rc = set_device(ws);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ws->stream));
+    for (auto& ev : ws->events) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, ev.a, ev.b) == hipSuccess) { ws->prof_ms[ev.kid] += t; ws->prof_cnt[ev.kid] += 1; }
+        (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b);
+    }
+    ws->events.clear();
+    for (int i = 0; i < N_KERNEL_IDS; ++i) { if (ms) ms[i] = ws->prof_ms[i]; if (launches) launches[i] = ws->prof_cnt[i]; }
+    return 0;
+}
+
+int ilqr_ws_info(ilqr_ws* ws, int32_t* W, int32_t* n_trials, int64_t* hbm_bytes)
+{
+    if (!ws) return fail(-1, "null workspace");
+    if (W) *W = ws->W;
+    if (n_trials) *n_trials = ws->n_trials;
+    if (hbm_bytes) *hbm_bytes = (int64_t)ws->hbm_bytes;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ one-shot host API
+#define TRY(expr) do { int rc_ = (expr); if (rc_) { if (ws) ilqr_ws_destroy(ws); return rc_; } } while (0)
+
+int ilqr_rollout_batched(const ilqr_desc* d, const double* init_state, const double* inputs_in, const double* params,
+                         double* states, double* inputs)
+{
+    ilqr_ws* ws = nullptr;
+    if (!init_state || !inputs_in || !params || !states || !inputs) return fail(-1, "null argument");
+    TRY(ilqr_ws_create(d, 0, &ws));
+    TRY(ilqr_ws_upload(ws, ILQR_F_INIT, init_state, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_PARAMS, params, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_INPUTS, inputs_in, 0));
+    TRY(ilqr_ws_rollout(ws));
+    TRY(ilqr_ws_download(ws, ILQR_F_STATES, states));
+    TRY(ilqr_ws_download(ws, ILQR_F_INPUTS, inputs));
+    return ilqr_ws_destroy(ws);
+}
+
+int ilqr_cost_batched(const ilqr_desc* d, const double* states, const double* inputs, const double* Rk, const double* QT,
+                      const double* target, double* cost)
+{
+    ilqr_ws* ws = nullptr;
+    if (!states || !inputs || !Rk || !QT || !target || !cost) return fail(-1, "null argument");
+    TRY(ilqr_ws_create(d, 0, &ws));
+    TRY(ilqr_ws_set_weights(ws, nullptr, Rk, QT));
+    TRY(ilqr_ws_upload(ws, ILQR_F_TARGET, target, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_STATES, states, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_INPUTS, inputs, 0));
+    TRY(ilqr_ws_cost(ws));
+    TRY(ilqr_ws_download(ws, ILQR_F_COST, cost));
+    return ilqr_ws_destroy(ws);
+}
+
+int ilqr_backward_batched(const ilqr_desc* d, const double* states, const double* inputs, const double* target,
+                          const double* Qk, const double* Rk, const double* QT, const double* params, double* k, double* K,
+                          double* dJ, int32_t* status)
+{
+    ilqr_ws* ws = nullptr;
+    if (!states || !inputs || !target || !Qk || !Rk || !QT || !params || !k || !K || !dJ) return fail(-1, "null argument");
+    TRY(ilqr_ws_create(d, 0, &ws));
+    TRY(ilqr_ws_set_weights(ws, Qk, Rk, QT));
+    TRY(ilqr_ws_upload(ws, ILQR_F_TARGET, target, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_PARAMS, params, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_STATES, states, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_INPUTS, inputs, 0));
+    // the stand-alone pass must not apply solve()'s "optimal" stop test: low_red = 0 never triggers it
+    ws->d.low_expected_reduction = 0.0;
+    TRY(ilqr_ws_backward(ws, 0));
+    TRY(ilqr_ws_download(ws, ILQR_F_KFF, k));
+    TRY(ilqr_ws_download(ws, ILQR_F_KFB, K));
+    TRY(ilqr_ws_download(ws, ILQR_F_DJ, dJ));
+    if (status) TRY(ilqr_ws_download(ws, ILQR_F_STATUS, status));
+    return ilqr_ws_destroy(ws);
+}
+
+int ilqr_forward_batched(const ilqr_desc* d, const double* init_state, const double* ref_states, const double* ref_inputs,
+                         const double* k, const double* K, const double* learning_rate, const double* params,
+                         double* states, double* inputs, const double* Rk, const double* QT, const double* target,
+                         double* cost)
+{
+    ilqr_ws* ws = nullptr;
+    if (!init_state || !ref_states || !ref_inputs || !k || !K || !learning_rate || !params || !states || !inputs)
+        return fail(-1, "null argument");
+    const bool with_cost = cost != nullptr;
+    if (with_cost && (!Rk || !QT || !target)) return fail(-1, "cost requested without Rk/QT/target");
+    TRY(ilqr_ws_create(d, 0, &ws));
+    if (with_cost) {
+        TRY(ilqr_ws_set_weights(ws, nullptr, Rk, QT));
+        TRY(ilqr_ws_upload(ws, ILQR_F_TARGET, target, 0));
+    }
+    TRY(ilqr_ws_upload(ws, ILQR_F_INIT, init_state, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_PARAMS, params, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_STATES, ref_states, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_INPUTS, ref_inputs, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_KFF, k, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_KFB, K, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_ALPHA, learning_rate, 0));
+    TRY(ilqr_ws_forward(ws, with_cost));
+    TRY(ilqr_ws_download(ws, ILQR_F_STATES_OUT, states));
+    TRY(ilqr_ws_download(ws, ILQR_F_INPUTS_OUT, inputs));
+    if (with_cost) TRY(ilqr_ws_download(ws, ILQR_F_NEW_COST, cost));
+    return ilqr_ws_destroy(ws);
+}
+
+int ilqr_solve_batched(const ilqr_desc* d, const double* init_state, const double* target, const double* guess,
+                       const double* Qk, const double* Rk, const double* QT, const double* params, double* states,
+                       double* inputs, double* k, double* K, double* cost, int32_t* iters, int32_t* status, double* trace)
+{
+    ilqr_ws* ws = nullptr;
+    if (!init_state || !target || !guess || !Qk || !Rk || !QT || !params) return fail(-1, "null argument");
+    TRY(ilqr_ws_create(d, trace != nullptr, &ws));
+    TRY(ilqr_ws_set_weights(ws, Qk, Rk, QT));
+    TRY(ilqr_ws_upload(ws, ILQR_F_INIT, init_state, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_TARGET, target, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_PARAMS, params, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_INPUTS, guess, 0));
+    TRY(ilqr_ws_solve(ws));
+    if (states) TRY(ilqr_ws_download(ws, ILQR_F_STATES, states));
+    if (inputs) TRY(ilqr_ws_download(ws, ILQR_F_INPUTS, inputs));
+    if (k) TRY(ilqr_ws_download(ws, ILQR_F_KFF, k));
+    if (K) TRY(ilqr_ws_download(ws, ILQR_F_KFB, K));
+    if (cost) TRY(ilqr_ws_download(ws, ILQR_F_COST, cost));
+    if (iters) TRY(ilqr_ws_download(ws, ILQR_F_ITERS, iters));
+    if (status) TRY(ilqr_ws_download(ws, ILQR_F_STATUS, status));
+    if (trace && ws->want_trace) TRY(ilqr_ws_download(ws, ILQR_F_TRACE, trace));
+    return ilqr_ws_destroy(ws);
+}
+
+int ltvlqr_batched(const ilqr_desc* d, int32_t n_state_rows, const double* states, const double* inputs, const double* Qk,
+                   const double* Rk, const double* QT, const double* params, double* K)
+{
+    ilqr_ws* ws = nullptr;
+    if (!states || !inputs || !Qk || !Rk || !QT || !params || !K) return fail(-1, "null argument");
+    if (!d) return fail(-1, "null descriptor");
+    if (n_state_rows < d->n_timesteps) return fail(-1, "states needs at least N=%d rows (got %d)", d->n_timesteps, n_state_rows);
+    TRY(ilqr_ws_create(d, 0, &ws));
+    TRY(ilqr_ws_set_weights(ws, Qk, Rk, QT));
+    TRY(ilqr_ws_upload(ws, ILQR_F_PARAMS, params, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_STATES, states, n_state_rows));
+    TRY(ilqr_ws_upload(ws, ILQR_F_INPUTS, inputs, 0));
+    TRY(ilqr_ws_ltvlqr(ws));
+    TRY(ilqr_ws_download(ws, ILQR_F_KFB, K));
+    return ilqr_ws_destroy(ws);
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+"""Drop-in for the reference's ``ilqr`` class (python/ilqr.py), computing on an AMD MI355X through libilqr_hip.so.
+
+Same constructor (14 positional arguments, ilqr.py:5), same methods and return values, same public
+attributes (trailing underscore), same progress prints for a single problem.  Additive extension: a leading
+batch axis -- ``init_state (B,n)``, ``initial_guess (B,N,m)`` and optionally ``target_state (B,n)``,
+``parameters (B,P)`` -- solves B independent problems at once; every output gains the leading ``B`` axis,
+``current_cost`` becomes ``(B,)`` and ``iterations_`` / ``status_`` report each problem's exit.
+
+All numerics happen in the HIP kernels (ilqr_amd/csrc/ilqr_hip.hip); there is no CPU path here.
+"""
+import numpy as np
+
+from . import _lib
+from .symbolic_dynamics import system_of
+
+
+class ilqr:
+    def __init__(self, init_state, target_state, initial_guess, dt, start_time, end_time, f_disc, A, B, Q_k, R_k, Q_T,
+                 parameters, n_iterations, device=0, n_alpha_parallel=0, verbose=None, zero_first_state=True):
+        self.init_state_ = init_state
+        self.target_state_ = target_state
+        self.inputs_ = initial_guess
+        self.batched_ = np.ndim(initial_guess) == 3
+        self.n_states_ = np.shape(init_state)[-1]                 # ilqr.py:9
+        self.n_inputs_ = np.shape(initial_guess)[-1]              # ilqr.py:10
+        self.batch_ = np.shape(initial_guess)[0] if self.batched_ else 1
+
+        self.dt_ = dt
+        self.start_time_ = start_time
+        self.end_time_ = end_time
+        self.time_span_ = np.arange(start_time, end_time, dt).flatten()   # ilqr.py:15
+        self.n_timesteps_ = np.shape(self.time_span_)[0]                  # ilqr.py:16
+        # Dynamics
+        self.f_ = f_disc
+        self.A_ = A
+        self.B_ = B
+        self.system_ = system_of(f_disc, A, B)
+        # Weighting
+        self.Q_k_ = Q_k
+        self.R_k_ = R_k
+        self.Q_T_ = Q_T
+        self.parameters_ = parameters
+        # Max iterations
+        self.n_iterations_ = n_iterations
+
+        # device-side options (not in the reference)
+        self.device_ = device
+        self.n_alpha_parallel_ = n_alpha_parallel
+        self.zero_first_state_ = zero_first_state
+        self.verbose_ = (not self.batched_) if verbose is None else verbose
+
+        n, m, npar = _lib.system_dims(self.system_)
+        if self.n_states_ != n or self.n_inputs_ != m:
+            raise ValueError('%s has %d states and %d inputs; got init_state with %d and initial_guess with %d'
+                             % (self.system_, n, m, self.n_states_, self.n_inputs_))
+        if np.shape(initial_guess)[-2] != self.n_timesteps_:
+            raise ValueError('initial_guess has %d rows but np.arange(start_time, end_time, dt) has %d steps'
+                             % (np.shape(initial_guess)[-2], self.n_timesteps_))
+        if np.size(parameters) % npar != 0:
+            raise ValueError('%s takes %d parameters' % (self.system_, npar))
+
+    # ------------------------------------------------------------------ helpers
+    def _b(self, a, tail_ndim):
+        """float64 contiguous with a leading batch axis."""
+        a = _lib.f64(a)
+        return a if a.ndim == tail_ndim + 1 else a[None]
+
+    def _unb(self, a):
+        return a if self.batched_ else a[0]
+
+    def _weights(self):
+        n, m = self.n_states_, self.n_inputs_
+        return (_lib.f64(self.Q_k_).reshape(n, n), _lib.f64(self.R_k_).reshape(m, m), _lib.f64(self.Q_T_).reshape(n, n))
+
+    def _target(self):
+        t = _lib.f64(self.target_state_)
+        return (t, True) if t.ndim == 2 else (t.reshape(-1), False)
+
+    def _params(self):
+        p = _lib.f64(self.parameters_)
+        return (p, True) if p.ndim == 2 else (p.reshape(-1), False)
+
+    def _desc(self, n_iterations=0):
+        _lib.require_gpu()
+        _, tb = self._target()
+        _, pb = self._params()
+        return _lib.make_desc(self.system_, self.n_timesteps_, self.batch_, self.dt_, n_iterations=n_iterations,
+                              n_alpha_parallel=self.n_alpha_parallel_, zero_first_state=self.zero_first_state_,
+                              device=self.device_, target_batched=tb, params_batched=pb)
+
+    # ------------------------------------------------------------------ ilqr.py:30-47
+    def rollout(self):
+        Bn, N, n, m = self.batch_, self.n_timesteps_, self.n_states_, self.n_inputs_
+        init = self._b(self.init_state_, 1)
+        u_in = self._b(self.inputs_, 2)
+        params, _ = self._params()
+        states = np.empty((Bn, N + 1, n))
+        inputs = np.empty((Bn, N, m))
+        _lib.check(_lib.lib().ilqr_rollout_batched(self._desc(), _lib.dptr(init), _lib.dptr(u_in), _lib.dptr(params),
+                                                   _lib.dptr(states), _lib.dptr(inputs)))
+        self.states_ = self._unb(states)
+        self.inputs_ = self._unb(inputs)
+        return self.states_, self.inputs_
+
+    # ------------------------------------------------------------------ ilqr.py:49-62
+    def compute_cost(self, states, inputs):
+        states = self._b(states, 2)
+        inputs = self._b(inputs, 2)
+        _, Rk, QT = self._weights()
+        target, _ = self._target()
+        cost = np.empty(self.batch_)
+        _lib.check(_lib.lib().ilqr_cost_batched(self._desc(), _lib.dptr(states), _lib.dptr(inputs), _lib.dptr(Rk),
+                                                _lib.dptr(QT), _lib.dptr(target), _lib.dptr(cost)))
+        return cost if self.batched_ else float(cost[0])
+
+    # ------------------------------------------------------------------ ilqr.py:64-135
+    def backwards_pass(self):
+        Bn, N, n, m = self.batch_, self.n_timesteps_, self.n_states_, self.n_inputs_
+        states = self._b(self.states_, 2)
+        inputs = self._b(self.inputs_, 2)
+        Qk, Rk, QT = self._weights()
+        target, _ = self._target()
+        params, _ = self._params()
+        k = np.empty((Bn, N, m))
+        K = np.empty((Bn, N, m, n))
+        dJ = np.empty((Bn, 3))
+        status = np.empty(Bn, dtype=np.int32)
+        _lib.check(_lib.lib().ilqr_backward_batched(self._desc(), _lib.dptr(states), _lib.dptr(inputs), _lib.dptr(target),
+                                                    _lib.dptr(Qk), _lib.dptr(Rk), _lib.dptr(QT), _lib.dptr(params),
+                                                    _lib.dptr(k), _lib.dptr(K), _lib.dptr(dJ), _lib.iptr(status)))
+        if not self.batched_ and status[0] == 3:
+            raise np.linalg.LinAlgError('Singular matrix')       # what np.linalg.inv raises at ilqr.py:106
+        self.expected_cost_reduction_grad_ = self._unb(dJ[:, 1])
+        self.expected_cost_reduction_hess_ = self._unb(dJ[:, 2])
+        self.expected_cost_reduction_ = self._unb(dJ[:, 0])
+        self.k_feedforward_ = self._unb(k)
+        self.K_feedback_ = self._unb(K)
+        return (self.k_feedforward_, self.K_feedback_, self.expected_cost_reduction_)
+
+    # ------------------------------------------------------------------ ilqr.py:137-158
+    def forwards_pass(self, learning_rate):
+        Bn, N, n, m = self.batch_, self.n_timesteps_, self.n_states_, self.n_inputs_
+        init = self._b(self.init_state_, 1)
+        ref_states = self._b(self.states_, 2)
+        ref_inputs = self._b(self.inputs_, 2)
+        k = self._b(self.k_feedforward_, 2)
+        K = self._b(self.K_feedback_, 3)
+        params, _ = self._params()
+        lr = np.ascontiguousarray(np.broadcast_to(np.asarray(learning_rate, dtype=np.float64), (Bn,)))
+        states = np.empty((Bn, N + 1, n))
+        inputs = np.empty((Bn, N, m))
+        _lib.check(_lib.lib().ilqr_forward_batched(self._desc(), _lib.dptr(init), _lib.dptr(ref_states),
+                                                   _lib.dptr(ref_inputs), _lib.dptr(k), _lib.dptr(K), _lib.dptr(lr),
+                                                   _lib.dptr(params), _lib.dptr(states), _lib.dptr(inputs), None, None,
+                                                   None, None))
+        return (self._unb(states), self._unb(inputs))
+
+    # ------------------------------------------------------------------ ilqr.py:159-211
+    def solve(self):
+        if self.n_iterations_ < 1:
+            # the reference falls off the loop with k_feedforward unbound (ilqr.py:211)
+            raise UnboundLocalError("local variable 'k_feedforward' referenced before assignment")
+        Bn, N, n, m = self.batch_, self.n_timesteps_, self.n_states_, self.n_inputs_
+        init = self._b(self.init_state_, 1)
+        guess = self._b(self.inputs_, 2)
+        Qk, Rk, QT = self._weights()
+        target, _ = self._target()
+        params, _ = self._params()
+        states = np.empty((Bn, N + 1, n))
+        inputs = np.empty((Bn, N, m))
+        k = np.empty((Bn, N, m))
+        K = np.empty((Bn, N, m, n))
+        cost = np.empty(Bn)
+        iters = np.empty(Bn, dtype=np.int32)
+        status = np.empty(Bn, dtype=np.int32)
+        trace = np.empty((Bn, self.n_iterations_, 6))
+        _lib.check(_lib.lib().ilqr_solve_batched(self._desc(self.n_iterations_), _lib.dptr(init), _lib.dptr(target),
+                                                 _lib.dptr(guess), _lib.dptr(Qk), _lib.dptr(Rk), _lib.dptr(QT),
+                                                 _lib.dptr(params), _lib.dptr(states), _lib.dptr(inputs), _lib.dptr(k),
+                                                 _lib.dptr(K), _lib.dptr(cost), _lib.iptr(iters), _lib.iptr(status),
+                                                 _lib.dptr(trace)))
+        if not self.batched_ and status[0] == 3:
+            raise np.linalg.LinAlgError('Singular matrix')
+        self.states_ = self._unb(states)
+        self.inputs_ = self._unb(inputs)
+        self.k_feedforward_ = self._unb(k)
+        self.K_feedback_ = self._unb(K)
+        self.iterations_ = self._unb(iters)
+        self.status_ = self._unb(status)
+        self.trace_ = self._unb(trace)
+        last = np.maximum(iters - 1, 0)
+        rows = trace[np.arange(Bn), last]
+        self.expected_cost_reduction_ = self._unb(rows[:, 1])
+        self.expected_cost_reduction_grad_ = self._unb(rows[:, 2])
+        self.expected_cost_reduction_hess_ = self._unb(rows[:, 3])
+        if self.verbose_:
+            self._print_progress(trace, iters, status)
+        current_cost = cost if self.batched_ else cost[0]
+        return self.states_, self.inputs_, self.k_feedforward_, self.K_feedback_, current_cost
+
+    def _print_progress(self, trace, iters, status):
+        """The reference's prints (ilqr.py:171,174,178,206), replayed from the device-side trace of problem 0."""
+        for ii in range(int(iters[0])):
+            print('Starting iteration: ', ii, ', Current cost: ', trace[0, ii, 0])
+            print('Expected cost reduction: ', trace[0, ii, 1])
+        if status[0] == 1:
+            print("Stopping optimization, optimal trajectory")
+        elif status[0] == 2:
+            print("Stopping optimization, low learning rate")

@@ -1,0 +1,161 @@
+/* include/ilqr_hip.h -- C ABI of libilqr_hip.so, the MI355X (gfx950) batched iLQR / LTV-LQR hot path.
+ *
+ * The reference (Kongx231/ilqr) has no FFI: its boundary is the python API of python/ilqr.py and
+ * python/ltvlqr.py.  Each entry point below is what a ctypes binding of that python API binds for one
+ * reference function; the citation says which (paths are relative to /root/reference).  The python
+ * drop-in classes in ilqr_amd/ are such a binding; INTEGRATION.md shows the stub a maintainer would add
+ * to the reference.
+ *
+ * Conventions
+ *   - Plain C, no C++/torch types.  Every function returns 0 on success and a negative code on error,
+ *     never throws, never aborts; ilqr_last_error() returns the message of the calling thread's last error.
+ *   - All arrays are C-contiguous float64 in the REFERENCE's numpy layout with one extra leading batch
+ *     axis B (B independent problems).  "host" pointers are ordinary host memory; the *_device variants
+ *     take HIP device pointers in the same layout.
+ *   - Inside the library trajectories live in HBM in a tiled structure-of-arrays layout
+ *     [tile = b/64][time][component][b%64]; the library converts at the boundary.
+ *   - n (states), m (inputs), P (parameters) are fixed by system_id; N = n_timesteps.
+ */
+#ifndef ILQR_HIP_H
+#define ILQR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ILQR_ABI_VERSION 1
+
+/* systems compiled into the library (sympy-generated __device__ dynamics, ilqr_amd/csrc/dynamics/) */
+enum { ILQR_SYS_PENDULUM = 0, ILQR_SYS_ACROBOT = 1, ILQR_SYS_CARTPOLE = 2, ILQR_SYS_QUADCOPTER = 3 };
+
+/* per-problem exit reason of solve(): python/ilqr.py:170-207 */
+enum {
+    ILQR_STATUS_MAX_ITER = 0,   /* loop ran n_iterations times (ilqr.py:170) */
+    ILQR_STATUS_OPTIMAL = 1,    /* |expected reduction| < low_expected_reduction (ilqr.py:175-179) */
+    ILQR_STATUS_LOW_LR = 2,     /* line search exhausted (ilqr.py:204-207) */
+    ILQR_STATUS_NUMERICAL = 3   /* Q_uu exactly singular / not positive definite (numpy would raise, ilqr.py:106) */
+};
+
+/* problem descriptor.  Fill with ilqr_desc_default() first. */
+typedef struct ilqr_desc {
+    int32_t system_id;            /* ILQR_SYS_* */
+    int32_t n_timesteps;          /* N = len(np.arange(start,end,dt)), ilqr.py:15-16 (computed by the caller) */
+    int64_t batch;                /* B >= 1 */
+    double dt;                    /* ilqr.py:12 */
+    int32_t n_iterations;         /* ilqr.py:28 */
+    int32_t n_alpha_parallel;     /* line-search trials evaluated concurrently per problem: 0 auto, else 1,2,4,...,64 */
+    int32_t zero_first_state;     /* 1 (default): row 0 of states is zero as in the reference (ilqr.py:31-42,143,153) */
+    int32_t device;               /* HIP device ordinal */
+    double learning_speed;        /* 0.95  ilqr.py:166 */
+    double low_learning_rate;     /* 0.05  ilqr.py:167 and the literal at :185 */
+    double low_expected_reduction;/* 1e-3  ilqr.py:168 */
+    double armijo_threshold;      /* 0.1   ilqr.py:169 */
+    double quu_reg;               /* added to diag(Q_uu); 0 = reference behaviour (ilqr.py:106 has none) */
+    int32_t target_batched;       /* 0: target_state is (n,) shared; 1: (B,n) */
+    int32_t params_batched;       /* 0: parameters is (P,) shared; 1: (B,P) */
+} ilqr_desc;
+
+void ilqr_desc_default(ilqr_desc* d);
+
+int ilqr_abi_version(void);
+int ilqr_device_count(void);
+const char* ilqr_last_error(void);
+/* name -> system id; also returns n, m, P.  Replaces the choice of symbolic_dynamics_<name>() (symbolic_dynamics.py:5,28). */
+int ilqr_system_lookup(const char* name, int32_t* n, int32_t* m, int32_t* n_params);
+int ilqr_system_dims(int32_t system_id, int32_t* n, int32_t* m, int32_t* n_params);
+
+/* The lambdified callables f_disc / A_disc / B_disc: python/symbolic_dynamics.py:23-25, 88-90.
+ * which: 0 f -> out (count,n); 1 A -> (count,n,n); 2 B -> (count,n,m).  x (count,n), u (count,m), params (P). */
+int ilqr_dynamics_eval(int32_t system_id, int32_t which, int64_t count, const double* x, const double* u, double dt,
+                       const double* params, double* out, int32_t device);
+
+/* ilqr.rollout(): python/ilqr.py:30-47.  init_state (B,n), inputs_in (B,N,m), params (P)|(B,P)
+ * -> states (B,N+1,n), inputs (B,N,m). */
+int ilqr_rollout_batched(const ilqr_desc* d, const double* init_state, const double* inputs_in, const double* params,
+                         double* states, double* inputs);
+
+/* ilqr.compute_cost(): python/ilqr.py:49-62.  states (B,N+1,n), inputs (B,N,m), target (n)|(B,n) -> cost (B). */
+int ilqr_cost_batched(const ilqr_desc* d, const double* states, const double* inputs, const double* Rk, const double* QT,
+                      const double* target, double* cost);
+
+/* ilqr.backwards_pass(): python/ilqr.py:64-135.  -> k (B,N,m), K (B,N,m,n),
+ * dJ (B,3) = {expected_cost_reduction_, _grad_, _hess_} (ilqr.py:128-130), status (B) 0 ok / ILQR_STATUS_NUMERICAL. */
+int ilqr_backward_batched(const ilqr_desc* d, const double* states, const double* inputs, const double* target,
+                          const double* Qk, const double* Rk, const double* QT, const double* params, double* k, double* K,
+                          double* dJ, int32_t* status);
+
+/* ilqr.forwards_pass(learning_rate): python/ilqr.py:137-158.  learning_rate (B).  Rk/QT/target/cost may all be NULL;
+ * when given, cost (B) = compute_cost(new states, new inputs). */
+int ilqr_forward_batched(const ilqr_desc* d, const double* init_state, const double* ref_states, const double* ref_inputs,
+                         const double* k, const double* K, const double* learning_rate, const double* params,
+                         double* states, double* inputs, const double* Rk, const double* QT, const double* target,
+                         double* cost);
+
+/* ilqr.solve(): python/ilqr.py:159-211.  Returns per problem what solve() returns (:211) plus iterations and exit reason.
+ * trace (optional, (B,n_iterations,6)): {cost at iteration start, expected reduction, _grad, _hess,
+ * accepted line-search trial j (alpha = learning_speed^j by repeated multiplication, -1 none), cost after}; NaN where not run. */
+int ilqr_solve_batched(const ilqr_desc* d, const double* init_state, const double* target, const double* guess,
+                       const double* Qk, const double* Rk, const double* QT, const double* params, double* states,
+                       double* inputs, double* k, double* K, double* cost, int32_t* iters, int32_t* status, double* trace);
+
+/* ltvlqr(): python/ltvlqr.py:3-28.  states (B,n_state_rows>=N,n) (rows 0..N-1 read), inputs (B,N,m) -> K (B,N,m,n).
+ * d->n_iterations and the line-search fields are ignored. */
+int ltvlqr_batched(const ilqr_desc* d, int32_t n_state_rows, const double* states, const double* inputs, const double* Qk,
+                   const double* Rk, const double* QT, const double* params, double* K);
+
+/* ---- device-resident workspace: the same passes with the batch kept in HBM between calls ----
+ * (no counterpart in the reference, whose arrays are numpy objects; this is the form bench.py and
+ * long-running callers use so that the timed region starts with inputs resident in HBM). */
+typedef struct ilqr_ws ilqr_ws;
+
+enum {  /* fields, reference layout with leading B */
+    ILQR_F_INIT = 0,      /* (B,n)        in  */
+    ILQR_F_TARGET = 1,    /* (n)|(B,n)    in  */
+    ILQR_F_PARAMS = 2,    /* (P)|(B,P)    in  */
+    ILQR_F_STATES = 3,    /* (B,N+1,n)    in/out */
+    ILQR_F_INPUTS = 4,    /* (B,N,m)      in/out (the initial guess goes here) */
+    ILQR_F_KFF = 5,       /* (B,N,m)      in/out */
+    ILQR_F_KFB = 6,       /* (B,N,m,n)    in/out */
+    ILQR_F_COST = 7,      /* (B) double   out */
+    ILQR_F_DJ = 8,        /* (B,3) double out */
+    ILQR_F_ITERS = 9,     /* (B) int32    out */
+    ILQR_F_STATUS = 10,   /* (B) int32    out */
+    ILQR_F_TRACE = 11,    /* (B,n_iterations,6) double out (only if created with want_trace) */
+    ILQR_F_LS_ROUNDS = 12,/* (B) int32 out: line-search rounds (of n_alpha_parallel trials) executed so far */
+    ILQR_F_ACCEPTS = 13,  /* (B) int32 out: accepted line-search steps so far */
+    ILQR_F_ALPHA = 14,    /* (B) double in: per-problem learning rate for ilqr_ws_forward */
+    ILQR_F_STATES_OUT = 15, /* (B,N+1,n) out of ilqr_ws_forward */
+    ILQR_F_INPUTS_OUT = 16, /* (B,N,m)   out of ilqr_ws_forward */
+    ILQR_F_NEW_COST = 17  /* (B) double out: cost of the last forward / accepted trial */
+};
+
+int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out);
+int ilqr_ws_destroy(ilqr_ws* ws);
+int ilqr_ws_set_weights(ilqr_ws* ws, const double* Qk, const double* Rk, const double* QT);   /* host pointers */
+int ilqr_ws_upload(ilqr_ws* ws, int32_t field, const void* host_src, int64_t rows_per_problem); /* rows: STATES only (0 = N+1) */
+int ilqr_ws_upload_device(ilqr_ws* ws, int32_t field, const void* dev_src, int64_t rows_per_problem);
+int ilqr_ws_download(ilqr_ws* ws, int32_t field, void* host_dst);
+int ilqr_ws_download_device(ilqr_ws* ws, int32_t field, void* dev_dst);
+/* passes; all asynchronous on the workspace stream, ilqr_ws_sync() waits */
+int ilqr_ws_reset(ilqr_ws* ws);            /* mark every problem active, zero iteration counters */
+int ilqr_ws_rollout(ilqr_ws* ws);          /* ilqr.py:30-47 + :49-62 (cost of the rollout) */
+int ilqr_ws_cost(ilqr_ws* ws);             /* ilqr.py:49-62 on STATES/INPUTS -> COST */
+int ilqr_ws_backward(ilqr_ws* ws, int32_t iteration);   /* ilqr.py:64-135 (+ the "optimal" test :175) */
+int ilqr_ws_linesearch(ilqr_ws* ws);       /* ilqr.py:180-202 without the accept copy: finds the first accepted trial */
+int ilqr_ws_accept(ilqr_ws* ws, int32_t iteration);     /* ilqr.py:194-207: re-rolls the accepted trial into STATES/INPUTS */
+int ilqr_ws_forward(ilqr_ws* ws, int32_t with_cost);    /* ilqr.py:137-158 with ALPHA -> STATES_OUT/INPUTS_OUT (+ NEW_COST) */
+int ilqr_ws_solve(ilqr_ws* ws);            /* ilqr.py:159-211: reset, rollout, n_iterations x (backward, linesearch, accept) */
+int ilqr_ws_ltvlqr(ilqr_ws* ws);           /* ltvlqr.py:3-28 on STATES/INPUTS -> KFB */
+int ilqr_ws_sync(ilqr_ws* ws);
+/* kernel timing with HIP events on the workspace stream.  kernel ids: 0 rollout, 1 backward, 2 linesearch, 3 accept,
+ * 4 ltvlqr, 5 forward, 6 cost.  ms[i] = summed duration, launches[i] = count since the last enable. */
+int ilqr_ws_profile(ilqr_ws* ws, int32_t enable);
+int ilqr_ws_profile_read(ilqr_ws* ws, double* ms /*8*/, int64_t* launches /*8*/);
+int ilqr_ws_info(ilqr_ws* ws, int32_t* n_alpha_parallel, int32_t* n_trials, int64_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,273 @@
+"""GPU parity tests: the HIP path (through the C ABI / the drop-in python classes) against
+(a) the committed golden fixtures produced by the reference python (tools/make_golden.py) and
+(b) the CPU oracle (oracle/ilqr_oracle.c) on seeded inputs.
+
+Bar (BASELINE.json north_star): 1e-8 relative on cost, states, inputs and gains, float64.
+``rel_err`` is max|a-b| / max|b| over the array.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-8
+SYSTEMS = ['pendulum', 'acrobot', 'cartpole', 'quadcopter']
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import ilqr_amd
+    ilqr_amd._lib.require_gpu()
+    return ilqr_amd
+
+
+def dyn(amd, system):
+    return getattr(amd, 'symbolic_dynamics_' + system)()
+
+
+def make_solver(amd, system, g, n_alpha_parallel=0, verbose=False, **over):
+    f, A, B = dyn(amd, system)
+    c = {k: g[k] for k in ('init', 'target', 'guess', 'Qk', 'Rk', 'QT', 'params')}
+    c.update(dt=float(g['dt']), start=float(g['start']), end=float(g['end']), n_iterations=int(g['n_iterations']))
+    c.update(over)
+    return amd.ilqr(c['init'], c['target'], c['guess'], c['dt'], c['start'], c['end'], f, A, B, c['Qk'], c['Rk'], c['QT'],
+                    c['params'], c['n_iterations'], verbose=verbose, n_alpha_parallel=n_alpha_parallel)
+
+
+# ------------------------------------------------------------------------------------------ dynamics
+@pytest.mark.parametrize('system', SYSTEMS)
+def test_dynamics_vs_lambdify(amd, system, oracle):
+    """f/A/B of the generated __device__ code vs the lambdified numpy callables (fixture) and the oracle."""
+    d = golden('dyn_' + system)
+    for which, fn in zip('fAB', dyn(amd, system)):
+        out = fn.batch(d['x'], d['u'], float(d['dt']), d['params'])
+        ref = d[which]
+        # device sin/cos (ocml) vs numpy's: a few ulp at most, scaled by the array magnitude
+        assert rel_err(out, ref) < 1e-13, (system, which)
+        assert rel_err(out, oracle.dynamics(system, which, d['x'], d['u'], float(d['dt']), d['params'])) < 1e-13
+
+
+@pytest.mark.parametrize('system', SYSTEMS)
+def test_dynamics_matlab_kat(amd, system):
+    """one-step known answers from the reference's MATLAB .mat trajectories"""
+    k = golden('mat_kat_' + system)
+    f = dyn(amd, system)[0]
+    out = f.batch(k['x'], k['u'], float(k['dt']), k['params'])
+    assert np.max(np.abs(out - k['x_next'])) < 1e-12
+
+
+def test_dynamics_single_point_shapes(amd):
+    f, A, B = amd.symbolic_dynamics_acrobot()
+    x, u, p = np.array([0.1, -0.2, 0.3, 0.4]), np.array([0.5]), np.array([1, 1, 2, 1, 9.8])
+    assert f(x, u, 0.001, p).shape == (4, 1) and A(x, u, 0.001, p).shape == (4, 4) and B(x, u, 0.001, p).shape == (4, 1)
+
+
+# ------------------------------------------------------------------------------------------ single passes
+@pytest.mark.parametrize('system', SYSTEMS)
+def test_rollout_and_cost(amd, system):
+    p = golden(system + '_passes')
+    s = make_solver(amd, system, p)
+    states, inputs = s.rollout()
+    assert np.all(states[0] == 0.0)                       # quirk: row 0 is never stored (ilqr.py:31-42)
+    assert rel_err(states, p['states0']) < TOL
+    assert np.array_equal(inputs, p['inputs0'])
+    c = s.compute_cost(states, inputs)
+    assert abs(c - float(p['cost0'])) <= TOL * abs(float(p['cost0']))
+
+
+@pytest.mark.parametrize('system', SYSTEMS)
+def test_backward_pass_teacher_forced(amd, system):
+    p = golden(system + '_passes')
+    s = make_solver(amd, system, p)
+    s.states_, s.inputs_ = p['states0'], p['inputs0']
+    k, K, dj = s.backwards_pass()
+    assert rel_err(k, p['k']) < TOL
+    assert rel_err(K, p['K']) < TOL
+    assert abs(dj - p['dJ'][0]) <= TOL * abs(p['dJ'][0])
+    assert abs(s.expected_cost_reduction_grad_ - p['dJ'][1]) <= TOL * abs(p['dJ'][1])
+    assert abs(s.expected_cost_reduction_hess_ - p['dJ'][2]) <= TOL * abs(p['dJ'][2])
+
+
+@pytest.mark.parametrize('system', SYSTEMS)
+def test_forward_pass_teacher_forced(amd, system):
+    p = golden(system + '_passes')
+    s = make_solver(amd, system, p)
+    s.states_, s.inputs_, s.k_feedforward_, s.K_feedback_ = p['states0'], p['inputs0'], p['k'], p['K']
+    stride = int(p['fwd_stride'])
+    for i, a in enumerate(p['alphas']):
+        st, u = s.forwards_pass(float(a))
+        assert np.all(st[0] == 0.0)
+        assert rel_err(np.vstack([st[::stride], st[-1:]]), p['fwd%d_states' % i]) < TOL
+        assert rel_err(np.vstack([u[::stride], u[-1:]]), p['fwd%d_inputs' % i]) < TOL
+        c = s.compute_cost(st, u)
+        assert abs(c - float(p['fwd%d_cost' % i])) <= TOL * abs(float(p['fwd%d_cost' % i]))
+
+
+# ------------------------------------------------------------------------------------------ solve()
+def check_solve(out, g, n_it_check=None):
+    states, inputs, k, K, cost = out
+    assert rel_err(states, g['states']) < TOL
+    assert rel_err(inputs, g['inputs']) < TOL
+    assert rel_err(K, g['K']) < TOL
+    # k shrinks towards zero at the optimum: compare it on the scale of the inputs it corrects
+    assert np.max(np.abs(k - g['k'])) < TOL * max(np.max(np.abs(g['k'])), np.max(np.abs(g['inputs'])))
+    assert abs(cost - float(g['cost'])) <= TOL * abs(float(g['cost']))
+
+
+@pytest.mark.parametrize('system', ['pendulum', 'acrobot', 'quadcopter'])
+def test_solve_example_config(amd, system):
+    """full solve() of the reference's example configuration vs the reference's own output"""
+    g = golden(system + '_solve')
+    s = make_solver(amd, system, g)
+    out = s.solve()
+    assert int(s.iterations_) == int(g['iters'])
+    assert int(s.status_) == int(g['status'])
+    tr = s.trace_[:int(g['iters'])]
+    assert np.array_equal(tr[:, 4], g['trace'][:, 4])      # same accepted line-search trial every iteration
+    assert rel_err(tr[:, 0], g['trace'][:, 0]) < TOL
+    check_solve(out, g)
+
+
+def test_solve_acrobot_reproduces_reference_csv(amd):
+    """the reference's committed acrobot_swingup_{states,inputs}.csv (written by example_acrobot_swingup.py:56-57 in 2021);
+    the reference itself re-run today differs from them by 1.3e-10."""
+    g = golden('acrobot_solve')
+    csv = golden('acrobot_csv')
+    s = make_solver(amd, 'acrobot', g)
+    states, inputs, _, _, _ = s.solve()
+    assert rel_err(states, csv['states']) < TOL
+    assert rel_err(inputs, csv['inputs']) < TOL
+
+
+def test_solve_cartpole_trace(amd):
+    """cartpole swing-up (R = 1e-4) amplifies rounding ~10x per iteration (the CPU oracle, which matches the reference's
+    dynamics bit for bit, is itself 1e-8 away from the reference after 7 iterations and flips an Armijo decision at
+    iteration 15), so the solve is compared iteration by iteration while the reference is still conditioned."""
+    g = golden('cartpole_solve')
+    s = make_solver(amd, 'cartpole', g, n_iterations=6)
+    s.solve()
+    tr = s.trace_
+    assert np.array_equal(tr[:6, 4], g['trace'][:6, 4])
+    assert rel_err(tr[:5, 0], g['trace'][:5, 0]) < TOL
+    assert rel_err(tr[:5, 1], g['trace'][:5, 1]) < TOL
+
+
+@pytest.mark.parametrize('system', SYSTEMS)
+def test_solve_batch_fixture(amd, system):
+    """8 seeded problems solved one by one by the reference (n_iterations=3) vs one batched call"""
+    g = golden(system + '_batch')
+    s = make_solver(amd, system, g)
+    states, inputs, k, K, cost = s.solve()
+    assert states.shape == g['states'].shape and K.shape == g['K'].shape
+    assert np.array_equal(s.status_, g['status'])
+    assert np.array_equal(s.iterations_, g['iters'])
+    assert np.array_equal(s.trace_[:, :, 4], g['trace'][:, :, 4])
+    for b in range(states.shape[0]):
+        check_solve((states[b], inputs[b], k[b], K[b], cost[b]), {key: g[key][b] for key in ('states', 'inputs', 'k', 'K', 'cost')})
+
+
+# ------------------------------------------------------------------------------------------ ltvlqr
+def test_ltvlqr_acrobot_csv(amd):
+    csv, g = golden('acrobot_csv'), golden('acrobot_ltvlqr')
+    _, A, B = amd.symbolic_dynamics_acrobot()
+    K = amd.ltvlqr(csv['states'], csv['inputs'], A, B, g['Qk'], g['Rk'], g['QT'], float(g['dt']), g['params'])
+    assert K.shape == (3000, 1, 4)
+    assert rel_err(K, g['K']) < TOL
+    # known answers quoted in SURVEY.md section 8c
+    assert np.allclose(K[0, 0], [44.6597152, 11.6235844, -15.68583313, -8.50586152], rtol=0, atol=1e-7)
+    assert np.allclose(K[2999, 0], [0.84717403, -1.37805551, 15.81263422, -47.35845942], rtol=0, atol=1e-7)
+
+
+def test_ltvlqr_pendulum(amd):
+    g = golden('pendulum_ltvlqr')
+    _, A, B = amd.symbolic_dynamics_pendulum()
+    K = amd.ltvlqr(g['states'], g['inputs'], A, B, g['Qk'], g['Rk'], g['QT'], float(g['dt']), g['params'])
+    assert rel_err(K, g['K']) < TOL
+    # exactly N rows of states is legal too (ltvlqr.py:17 reads rows 0..N-1 only)
+    K2 = amd.ltvlqr(g['states'][:-1], g['inputs'], A, B, g['Qk'], g['Rk'], g['QT'], float(g['dt']), g['params'])
+    assert np.array_equal(K, K2)
+
+
+# ------------------------------------------------------------------------------------------ vs the oracle, seeded
+def random_batch(system, B, N, seed):
+    g = golden(system + '_batch')
+    rng = np.random.default_rng(seed)
+    n, m = g['init'].shape[1], g['guess'].shape[2]
+    init = g['init'][0] + rng.uniform(-0.2, 0.2, (B, n))
+    guess = np.resize(g['guess'][0], (N, m))[None] + 0.05 * rng.standard_normal((B, N, m))
+    return g, init, guess
+
+
+@pytest.mark.parametrize('system,B,N', [('pendulum', 130, 150), ('acrobot', 65, 200), ('cartpole', 64, 120), ('quadcopter', 5, 40)])
+def test_solve_vs_oracle_ragged_batch(amd, oracle, system, B, N):
+    """batch sizes that are not multiples of the 64-problem tile; per-problem targets and parameters"""
+    g, init, guess = random_batch(system, B, N, seed=11)
+    rng = np.random.default_rng(5)
+    target = g['target'][None] + rng.uniform(-0.05, 0.05, (B, len(g['target'])))
+    params = g['params'][None] * (1.0 + rng.uniform(-0.02, 0.02, (B, len(g['params']))))
+    dt = float(g['dt'])
+    f, A, Bf = dyn(amd, system)
+    s = amd.ilqr(init, target, guess, dt, 0.0, N * dt - dt / 2, f, A, Bf, g['Qk'], g['Rk'], g['QT'], params, 3)
+    assert s.n_timesteps_ == N
+    states, inputs, k, K, cost = s.solve()
+    ref = [oracle.solve(system, init[b], target[b], guess[b], g['Qk'], g['Rk'], g['QT'], dt, params[b], 3) for b in range(B)]
+    assert np.array_equal(s.status_, [r['status'] for r in ref])
+    assert np.array_equal(s.iterations_, [r['iters'] for r in ref])
+    for b in range(B):
+        assert np.array_equal(s.trace_[b, :, 4][:ref[b]['iters']], ref[b]['trace'][:ref[b]['iters'], 4]), b
+        check_solve((states[b], inputs[b], k[b], K[b], cost[b]), ref[b])
+
+
+def test_alpha_width_does_not_change_results(amd):
+    """the number of concurrently evaluated line-search trials is a scheduling choice: same accepted trial, same bits"""
+    g, init, guess = random_batch('acrobot', 9, 150, seed=3)
+    f, A, Bf = dyn(amd, 'acrobot')
+    outs = []
+    for W in (1, 8, 64):
+        s = amd.ilqr(init, g['target'], guess, float(g['dt']), 0.0, 150 * float(g['dt']) - 1e-9, f, A, Bf, g['Qk'], g['Rk'],
+                     g['QT'], g['params'], 4, n_alpha_parallel=W)
+        outs.append(s.solve() + (s.trace_.copy(),))
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_ltvlqr_vs_oracle_batch(amd, oracle):
+    csv, g = golden('acrobot_csv'), golden('acrobot_ltvlqr')
+    rng = np.random.default_rng(1)
+    B, N = 70, 400
+    states = csv['states'][None, :N + 1] + 1e-2 * rng.standard_normal((B, N + 1, 4))
+    inputs = csv['inputs'][None, :N] + 1e-1 * rng.standard_normal((B, N, 1))
+    _, A, Bf = amd.symbolic_dynamics_acrobot()
+    K = amd.ltvlqr(states, inputs, A, Bf, g['Qk'], g['Rk'], g['QT'], float(g['dt']), g['params'])
+    Ko = oracle.ltvlqr_batched('acrobot', states, inputs, g['Qk'], g['Rk'], g['QT'], float(g['dt']), g['params'])
+    for b in range(B):
+        assert rel_err(K[b], Ko[b]) < TOL
+
+
+# ------------------------------------------------------------------------------------------ API behaviour
+def test_errors_are_reported_not_thrown(amd):
+    from ilqr_amd import _lib
+    d = _lib.make_desc('acrobot', 10, 0, 0.001)
+    with pytest.raises(_lib.IlqrHipError):
+        _lib.Workspace('acrobot', 10, 0, 0.001)
+    assert _lib.lib().ilqr_ws_create(d, 0, None) < 0
+    assert b'batch' in _lib.lib().ilqr_last_error()
+    with pytest.raises(TypeError):
+        amd.ilqr(np.zeros(2), np.zeros(2), np.zeros((10, 1)), 0.1, 0, 1, lambda *a: 0, lambda *a: 0, lambda *a: 0,
+                 np.eye(2), np.eye(1), np.eye(2), np.ones(3), 1)
+    f, A, B = amd.symbolic_dynamics_pendulum()
+    with pytest.raises(UnboundLocalError):          # the reference's behaviour for n_iterations == 0 (ilqr.py:211)
+        amd.ilqr(np.zeros(2), np.zeros(2), np.zeros((10, 1)), 0.1, 0, 1, f, A, B, np.eye(2), np.eye(1), np.eye(2),
+                 np.ones(3), 0).solve()
+
+
+def test_solve_prints_like_the_reference(amd, capsys):
+    g = golden('pendulum_solve')
+    s = make_solver(amd, 'pendulum', g, verbose=True)
+    s.solve()
+    out = capsys.readouterr().out
+    assert out.count('Starting iteration: ') == int(g['iters'])
+    assert 'Stopping optimization, optimal trajectory' in out
