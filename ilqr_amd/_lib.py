@@ -17,7 +17,7 @@ STATUS_NAMES = {0: 'max_iter', 1: 'optimal', 2: 'low_learning_rate', 3: 'numeric
 
 # fields of the device-resident workspace (include/ilqr_hip.h)
 F_INIT, F_TARGET, F_PARAMS, F_STATES, F_INPUTS, F_KFF, F_KFB, F_COST, F_DJ, F_ITERS, F_STATUS, F_TRACE, \
-    F_LS_ROUNDS, F_ACCEPTS, F_ALPHA, F_STATES_OUT, F_INPUTS_OUT, F_NEW_COST = range(18)
+    F_LS_ROUNDS, F_ACCEPTS, F_ALPHA, F_STATES_OUT, F_INPUTS_OUT, F_NEW_COST, F_GUESS = range(19)
 KERNEL_NAMES = ('rollout', 'backward', 'linesearch', 'accept', 'ltvlqr', 'forward', 'cost', 'unused')
 
 
@@ -187,7 +187,7 @@ class Workspace:
                 F_PARAMS: (B, P) if self.desc.params_batched else (P,), F_STATES: (B, N + 1, n),
                 F_INPUTS: (B, N, m), F_KFF: (B, N, m), F_KFB: (B, N, m, n), F_COST: (B,), F_DJ: (B, 3), F_ITERS: (B,),
                 F_STATUS: (B,), F_TRACE: (B, self.n_iterations, 6), F_LS_ROUNDS: (B,), F_ACCEPTS: (B,), F_ALPHA: (B,),
-                F_STATES_OUT: (B, N + 1, n), F_INPUTS_OUT: (B, N, m), F_NEW_COST: (B,)}[field]
+                F_STATES_OUT: (B, N + 1, n), F_INPUTS_OUT: (B, N, m), F_NEW_COST: (B,), F_GUESS: (B, N, m)}[field]
 
     def set_weights(self, Qk, Rk, QT):
         n, m = self.n, self.m

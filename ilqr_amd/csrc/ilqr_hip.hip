@@ -78,6 +78,7 @@ struct KArgs {
     double dt, low_red, armijo_thr, quu_reg;
     double* X;             // [tile][state_rows][n][64]
     double* U;             // [tile][N][m][64]
+    const double* G;       // [tile][N][m][64] initial guess (read by k_rollout only)
     double* KFB;           // [tile][N][m*n][64]
     double* KFF;           // [tile][N][m][64]
     double* XO;            // forward outputs (may alias X/U)
@@ -381,7 +382,8 @@ __global__ void __launch_bounds__(64) k_rollout(const KArgs a)
     load_uniform<m * m>(a.WTS + n * n, Rk);
     load_uniform<n * n>(a.WTS + n * n + m * m, QT);
     double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
-    const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+    const double* Gp = a.G + (size_t)tile * a.N * m * TILE + lane;
+    double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
     {
         double x0[n];
 #pragma unroll
@@ -391,12 +393,13 @@ __global__ void __launch_bounds__(64) k_rollout(const KArgs a)
     double cost = 0.0;
     for (int t = 0; t < a.N; ++t) {
         double u[m], xn[n];
-        load_col<m>(Up + (size_t)t * m * TILE, u);
+        load_col<m>(Gp + (size_t)t * m * TILE, u);
         cost = cost + input_cost<m>(u, Rk);
         S::f(x, u, a.dt, p, xn);
 #pragma unroll
         for (int i = 0; i < n; ++i) x[i] = xn[i];
-        store_col<n>(Xp + (size_t)(t + 1) * n * TILE, x);
+        store_col<n>(Xp + (size_t)(t + 1) * n * TILE, x);                              // :39
+        store_col<m>(Up + (size_t)t * m * TILE, u);                                    // :40
     }
     cost = cost + terminal_cost<n>(x, target, QT);
     a.cost[b] = cost;
@@ -895,7 +898,7 @@ struct ilqr_ws {
     int n, m, np, N, W, n_trials, want_trace;
     long long B, Bpad, tiles;
     hipStream_t stream;
-    double *X, *U, *KFB, *KFF, *XO, *UO, *INIT, *TARGET, *PARAMS, *WTS, *alphas, *alpha_pp, *cost, *new_cost, *dJ, *trace;
+    double *X, *U, *G, *KFB, *KFF, *XO, *UO, *INIT, *TARGET, *PARAMS, *WTS, *alphas, *alpha_pp, *cost, *new_cost, *dJ, *trace;
     int *active, *iters, *status, *acc_j, *ls_rounds, *accepts;
     void* staging;
     size_t staging_bytes;
@@ -918,7 +921,7 @@ KArgs make_args(ilqr_ws* ws, int it)
     a.n_trials = ws->n_trials; a.state_rows = ws->state_rows; a.n_tiles = ws->tiles;
     a.dt = ws->d.dt; a.low_red = ws->d.low_expected_reduction; a.armijo_thr = ws->d.armijo_threshold;
     a.quu_reg = ws->d.quu_reg;
-    a.X = ws->X; a.U = ws->U; a.KFB = ws->KFB; a.KFF = ws->KFF; a.XO = ws->X; a.UO = ws->U;
+    a.X = ws->X; a.U = ws->U; a.G = ws->G; a.KFB = ws->KFB; a.KFF = ws->KFF; a.XO = ws->X; a.UO = ws->U;
     a.INIT = ws->INIT; a.TARGET = ws->TARGET; a.PARAMS = ws->PARAMS; a.WTS = ws->WTS; a.alphas = ws->alphas;
     a.alpha_pp = ws->alpha_pp; a.cost = ws->cost; a.new_cost = ws->new_cost; a.dJ = ws->dJ; a.active = ws->active;
     a.iters = ws->iters; a.status = ws->status; a.acc_j = ws->acc_j; a.ls_rounds = ws->ls_rounds;
@@ -989,6 +992,7 @@ size_t field_elems(const ilqr_ws* ws, int field, int* is_int, long long* tc_out,
         case ILQR_F_PARAMS: tc = np; *dptr = ws->PARAMS; break;
         case ILQR_F_STATES: tc = (long long)ws->state_rows * n; *dptr = ws->X; break;
         case ILQR_F_INPUTS: tc = N * m; *dptr = ws->U; break;
+        case ILQR_F_GUESS: tc = N * m; *dptr = ws->G; break;
         case ILQR_F_KFF: tc = N * m; *dptr = ws->KFF; break;
         case ILQR_F_KFB: tc = N * m * n; *dptr = ws->KFB; break;
         case ILQR_F_COST: tc = 1; *dptr = ws->cost; break;
@@ -1261,7 +1265,7 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
     ws->W = W;
     const size_t Bp = (size_t)ws->Bpad, n = ws->n, m = ws->m, np = ws->np, N = ws->N;
     struct { void** p; size_t bytes; } allocs[] = {
-        {(void**)&ws->X, Bp * (N + 1) * n * 8}, {(void**)&ws->U, Bp * N * m * 8}, {(void**)&ws->KFB, Bp * N * m * n * 8},
+        {(void**)&ws->X, Bp * (N + 1) * n * 8}, {(void**)&ws->U, Bp * N * m * 8}, {(void**)&ws->G, Bp * N * m * 8}, {(void**)&ws->KFB, Bp * N * m * n * 8},
         {(void**)&ws->KFF, Bp * N * m * 8}, {(void**)&ws->INIT, Bp * n * 8}, {(void**)&ws->TARGET, Bp * n * 8},
         {(void**)&ws->PARAMS, Bp * np * 8}, {(void**)&ws->WTS, (2 * n * n + m * m) * 8}, {(void**)&ws->alphas, MAX_TRIALS * 8},
         {(void**)&ws->alpha_pp, Bp * 8}, {(void**)&ws->cost, Bp * 8}, {(void**)&ws->new_cost, Bp * 8}, {(void**)&ws->dJ, 3 * Bp * 8},
@@ -1290,6 +1294,7 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
     HIPCHK(hipMemsetAsync(ws->KFF, 0, Bp * N * m * 8, ws->stream));
     HIPCHK(hipMemsetAsync(ws->X, 0, Bp * (N + 1) * n * 8, ws->stream));
     HIPCHK(hipMemsetAsync(ws->U, 0, Bp * N * m * 8, ws->stream));
+    HIPCHK(hipMemsetAsync(ws->G, 0, Bp * N * m * 8, ws->stream));
     HIPCHK(hipMemsetAsync(ws->cost, 0, Bp * 8, ws->stream));
     HIPCHK(hipMemsetAsync(ws->new_cost, 0, Bp * 8, ws->stream));
     HIPCHK(hipMemsetAsync(ws->TARGET, 0, Bp * n * 8, ws->stream));
@@ -1306,7 +1311,7 @@ int ilqr_ws_destroy(ilqr_ws* ws)
     (void)hipSetDevice(ws->d.device);
     if (ws->stream) (void)hipStreamSynchronize(ws->stream);
     for (auto& ev : ws->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    void* ptrs[] = {ws->X, ws->U, ws->KFB, ws->KFF, ws->XO, ws->UO, ws->INIT, ws->TARGET, ws->PARAMS, ws->WTS, ws->alphas,
+    void* ptrs[] = {ws->X, ws->U, ws->G, ws->KFB, ws->KFF, ws->XO, ws->UO, ws->INIT, ws->TARGET, ws->PARAMS, ws->WTS, ws->alphas,
                     ws->alpha_pp, ws->cost, ws->new_cost, ws->dJ, ws->trace, ws->active, ws->iters, ws->status, ws->acc_j,
                     ws->ls_rounds, ws->accepts, ws->staging};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1499,7 +1504,7 @@ int ilqr_rollout_batched(const ilqr_desc* d, const double* init_state, const dou
     TRY(ilqr_ws_create(d, 0, &ws));
     TRY(ilqr_ws_upload(ws, ILQR_F_INIT, init_state, 0));
     TRY(ilqr_ws_upload(ws, ILQR_F_PARAMS, params, 0));
-    TRY(ilqr_ws_upload(ws, ILQR_F_INPUTS, inputs_in, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_GUESS, inputs_in, 0));
     TRY(ilqr_ws_rollout(ws));
     TRY(ilqr_ws_download(ws, ILQR_F_STATES, states));
     TRY(ilqr_ws_download(ws, ILQR_F_INPUTS, inputs));
@@ -1583,7 +1588,7 @@ int ilqr_solve_batched(const ilqr_desc* d, const double* init_state, const doubl
     TRY(ilqr_ws_upload(ws, ILQR_F_INIT, init_state, 0));
     TRY(ilqr_ws_upload(ws, ILQR_F_TARGET, target, 0));
     TRY(ilqr_ws_upload(ws, ILQR_F_PARAMS, params, 0));
-    TRY(ilqr_ws_upload(ws, ILQR_F_INPUTS, guess, 0));
+    TRY(ilqr_ws_upload(ws, ILQR_F_GUESS, guess, 0));
     TRY(ilqr_ws_solve(ws));
     if (states) TRY(ilqr_ws_download(ws, ILQR_F_STATES, states));
     if (inputs) TRY(ilqr_ws_download(ws, ILQR_F_INPUTS, inputs));

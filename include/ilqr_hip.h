@@ -115,7 +115,7 @@ enum {  /* fields, reference layout with leading B */
     ILQR_F_TARGET = 1,    /* (n)|(B,n)    in  */
     ILQR_F_PARAMS = 2,    /* (P)|(B,P)    in  */
     ILQR_F_STATES = 3,    /* (B,N+1,n)    in/out */
-    ILQR_F_INPUTS = 4,    /* (B,N,m)      in/out (the initial guess goes here) */
+    ILQR_F_INPUTS = 4,    /* (B,N,m)      in/out (the current trajectory's inputs) */
     ILQR_F_KFF = 5,       /* (B,N,m)      in/out */
     ILQR_F_KFB = 6,       /* (B,N,m,n)    in/out */
     ILQR_F_COST = 7,      /* (B) double   out */
@@ -128,7 +128,8 @@ enum {  /* fields, reference layout with leading B */
     ILQR_F_ALPHA = 14,    /* (B) double in: per-problem learning rate for ilqr_ws_forward */
     ILQR_F_STATES_OUT = 15, /* (B,N+1,n) out of ilqr_ws_forward */
     ILQR_F_INPUTS_OUT = 16, /* (B,N,m)   out of ilqr_ws_forward */
-    ILQR_F_NEW_COST = 17  /* (B) double out: cost of the last forward / accepted trial */
+    ILQR_F_NEW_COST = 17, /* (B) double out: cost of the last forward / accepted trial */
+    ILQR_F_GUESS = 18     /* (B,N,m)      in: initial guess read by rollout()/solve(); kept, so solve() can be repeated */
 };
 
 int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out);
