@@ -14,15 +14,26 @@ source with ``ast`` and re-emits the same expression tree in C:
 * same literals (15-significant-digit decimals printed by sympy's StrPrinter;
   ``1/2`` stays a division of two exact constants),
 * ``x**2`` becomes ``x*x`` (numpy's scalar pow is within 1 ulp of it),
-* ``sin/cos/tan`` calls are hoisted into named temporaries, one per distinct
-  argument, so host libm / device ocml are called once per argument.
+* ``sin/cos`` calls are hoisted, one ``ILQR_DYN_SINCOS(arg, s, c)`` per distinct
+  argument (the includer maps it to libm sin+cos in the oracle and to the shared
+  range reduction of ``fast_trig.h`` on the device; an unused half is dead code),
+  ``tan`` goes through ``ILQR_DYN_TAN``.  After the hoisted calls ONE branch
+  ``if (ILQR_DYN_TRIG_BIG(a0) || ...) { ILQR_DYN_SINCOS_SLOW(...) }`` lets the device
+  patch huge / non-finite arguments with the general ocml routines (never taken
+  on sane trajectories; the oracle defines TRIG_BIG as 0),
+* ``a / d`` becomes ``ILQR_DYN_DIV(a, d, rdK)`` with one hoisted ``rdK = ILQR_DYN_RCP(d)``
+  per distinct non-constant divisor: the oracle defines DIV as the plain ``a / d``
+  (so it stays bit-identical to numpy); the device shares the reciprocal among the
+  many quotients with the same divisor and corrects each quotient with one fused
+  residual step (q = a*r; q += (a - d*q)*r), which reproduces the correctly rounded
+  IEEE quotient except in rare half-ulp cases.
 
 Common sub-expression elimination is left to the C compiler, which is value
 preserving under ``-ffp-contract=off`` (no re-association, no contraction).
 
 Output: ``ilqr_amd/csrc/dynamics/<system>.h``.  The includer defines
-``ILQR_DYN_FN`` (function qualifiers) and ``ILQR_DYN_CONST`` (qualifier of the
-sparsity tables) -- hipcc for gfx950 in ``ilqr_hip.hip``, gcc in ``oracle/``.
+``ILQR_DYN_FN`` (function qualifiers), ``ILQR_DYN_CONST`` (qualifier of the
+sparsity tables), ``ILQR_DYN_SINCOS`` and ``ILQR_DYN_TAN`` -- hipcc for gfx950 in ``ilqr_hip.hip``, gcc in ``oracle/``.
 The generated headers are committed: the GPU box never runs sympy.
 """
 import ast
@@ -62,8 +73,11 @@ class _Emitter:
             elif isinstance(st, ast.Return):
                 self.ret = st.value
         assert self.ret is not None
-        self.trig = {}       # "sin(x[1])" -> temp name
+        self.trig = {}       # C text of a sin/cos argument -> index of its (sn_i, cs_i) pair
         self.trig_defs = []  # ordered definitions
+        self.trig_args = []  # sin/cos arguments in order of first use
+        self.rcp = {}        # C text of a divisor -> index of its hoisted reciprocal
+        self.rcp_defs = []
 
     def elements(self):
         call = self.ret
@@ -78,7 +92,9 @@ class _Emitter:
         if isinstance(e, ast.BinOp):
             if isinstance(e.op, ast.Pow):
                 return self.power(e.left, e.right)
-            op = {ast.Add: '+', ast.Sub: '-', ast.Mult: '*', ast.Div: '/'}[type(e.op)]
+            if isinstance(e.op, ast.Div):
+                return self.divide(e.left, e.right)
+            op = {ast.Add: '+', ast.Sub: '-', ast.Mult: '*'}[type(e.op)]
             return '(%s %s %s)' % (self.expr(e.left), op, self.expr(e.right))
         if isinstance(e, ast.UnaryOp):
             if isinstance(e.op, ast.USub):
@@ -95,15 +111,34 @@ class _Emitter:
         if isinstance(e, ast.Call):
             fname = e.func.id if isinstance(e.func, ast.Name) else e.func.attr
             assert fname in _FUNCS and len(e.args) == 1, ast.dump(e)
-            key = '%s(%s)' % (_FUNCS[fname], self.expr(e.args[0]))
-            if fname in ('sin', 'cos', 'tan'):
+            arg = self.expr(e.args[0])
+            if fname in ('sin', 'cos'):
+                if arg not in self.trig:
+                    i = len(self.trig)
+                    self.trig[arg] = i
+                    self.trig_defs.append('double sn%d, cs%d; ILQR_DYN_SINCOS(%s, sn%d, cs%d); (void)sn%d; (void)cs%d;' % (i, i, arg, i, i, i, i))
+                    self.trig_args.append((arg, i))
+                return ('sn%d' if fname == 'sin' else 'cs%d') % self.trig[arg]
+            if fname == 'tan':
+                key = 'tan:' + arg
                 if key not in self.trig:
-                    t = 'tr%d' % len(self.trig)
-                    self.trig[key] = t
-                    self.trig_defs.append('const double %s = %s;' % (t, key))
-                return self.trig[key]
-            return key
+                    i = len(self.trig)
+                    self.trig[key] = i
+                    self.trig_defs.append('const double tn%d = ILQR_DYN_TAN(%s);' % (i, arg))
+                return 'tn%d' % self.trig[key]
+            return '%s(%s)' % (_FUNCS[fname], arg)
         raise NotImplementedError(ast.dump(e))
+
+    def divide(self, num, den):
+        """a / d -> ILQR_DYN_DIV(a, d, rdK) with one hoisted reciprocal per distinct divisor (see the header comment)."""
+        n = self.expr(num)
+        if isinstance(den, ast.Constant):
+            return '(%s / %s)' % (n, self.expr(den))            # constant divisor: folded or a plain division
+        d = self.expr(den)
+        if d not in self.rcp:
+            self.rcp[d] = len(self.rcp)
+            self.rcp_defs.append('const double rd%d = ILQR_DYN_RCP(%s); (void)rd%d;' % (self.rcp[d], d, self.rcp[d]))
+        return 'ILQR_DYN_DIV(%s, %s, rd%d)' % (n, d, self.rcp[d])
 
     def power(self, base, expo):
         b = self.expr(base)
@@ -142,6 +177,14 @@ def _function(model, what, mat):
     lines.append('    (void)x; (void)u; (void)dt; (void)p;')
     for d in em.trig_defs:
         lines.append('    ' + d)
+    if em.trig_args:
+        # one rarely-taken branch for all arguments of this function (keeps the fast paths in one basic block)
+        lines.append('    if (%s) {' % ' || '.join('ILQR_DYN_TRIG_BIG(%s)' % a for a, _ in em.trig_args))
+        for a, i in em.trig_args:
+            lines.append('        ILQR_DYN_SINCOS_SLOW(%s, sn%d, cs%d);' % (a, i, i))
+        lines.append('    }')
+    for d in em.rcp_defs:
+        lines.append('    ' + d)
     k = 0
     for row in els:
         for e in row:
@@ -161,7 +204,9 @@ def generate(name):
                  ' * python source sympy.lambdify would run (same expression tree, same literals).\n'
                  ' * Reference: /root/reference/python/symbolic_dynamics.py:23-25,88-90 (lambdify call sites).\n'
                  ' * Row-major: f out[n], A out[n*n] (A[i][j] = out[i*n+j]), B out[n*m].\n'
-                 ' * The includer defines ILQR_DYN_FN and ILQR_DYN_CONST and must compile with -ffp-contract=off. */'
+                 ' * The includer defines ILQR_DYN_FN, ILQR_DYN_CONST, ILQR_DYN_SINCOS(x, s, c), ILQR_DYN_SINCOS_SLOW(x, s, c),\n'
+                 ' * ILQR_DYN_TRIG_BIG(x), ILQR_DYN_TAN(x), ILQR_DYN_RCP(d), ILQR_DYN_DIV(a, d, rd) and must compile\n'
+                 ' * with -ffp-contract=off. */'
                  % (name, name))
     parts.append('#ifndef ILQR_DYN_%s_H\n#define ILQR_DYN_%s_H' % (up, up))
     parts.append('#define ILQR_DYN_%s_ID %d\n#define ILQR_DYN_%s_N %d\n#define ILQR_DYN_%s_M %d\n#define ILQR_DYN_%s_NP %d'

@@ -30,6 +30,14 @@
 
 #define ILQR_DYN_FN static inline
 #define ILQR_DYN_CONST static const
+/* numpy's sin/cos are glibc's: one libm call each, as the lambdified callables make */
+#define ILQR_DYN_SINCOS(x, s, c) do { (s) = sin(x); (c) = cos(x); } while (0)
+#define ILQR_DYN_SINCOS_SLOW(x, s, c) do { } while (0)
+#define ILQR_DYN_TRIG_BIG(x) 0
+#define ILQR_DYN_TAN(x) tan(x)
+/* plain IEEE division, as numpy does; the hoisted reciprocal is a device-side device and unused here */
+#define ILQR_DYN_RCP(d) 0.0
+#define ILQR_DYN_DIV(a, d, rd) ((a) / (d))
 #include "../ilqr_amd/csrc/dynamics/pendulum.h"
 #include "../ilqr_amd/csrc/dynamics/acrobot.h"
 #include "../ilqr_amd/csrc/dynamics/cartpole.h"
