@@ -166,8 +166,11 @@ def main():
     kern = {}
     for name, bytes_, flops_ in (('backward', tot['bwd'] * N * work['bwd_bytes'], tot['bwd'] * N * work['bwd_flops']),
                                  ('linesearch', tot['rounds'] * N * work['fwd_round_bytes'], tot['trials'] * N * work['fwd_flops']),
-                                 ('accept', tot['accepts'] * N * work['accept_bytes'], tot['accepts'] * N * work['fwd_flops'])):
+                                 ('accept', tot['accepts'] * N * work['accept_bytes'], tot['accepts'] * N * work['fwd_flops']),
+                                 ('linearize', 0, 0), ('rollout', 0, 0)):
         ms, cnt = prof[name]
+        if cnt == 0:
+            continue
         per_launch_ms = ms / max(cnt, 1)
         launches_per_step = cnt / max(args.steps, 1)
         b_launch = bytes_ / max(launches_per_step, 1)
@@ -193,14 +196,14 @@ def main():
 
     total_solves = B * world * args.steps
     value = total_solves / elapsed
-    pass_ms = sum(kern[k_]['ms_per_launch'] for k_ in ('backward', 'linesearch', 'accept'))
+    pass_ms = sum(kern[k_]['ms_per_launch'] for k_ in ('backward', 'linesearch', 'accept', 'linearize') if k_ in kern)
     out = {
         'metric': 'iLQR solves/sec (fixed iters, batched)', 'value': round(value, 2), 'unit': 'solves/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': 'acrobot swing-up iLQR (BASELINE configs[1]): n=4 m=1 N=%d, B=%d problems per GPU, '
                                '%d iterations, reference line search + stop tests active' % (N, B, args.iterations),
-                   'problems_per_gpu': B, 'n_timesteps': N, 'n_iterations': args.iterations, 'n_alpha_parallel': W,
+                   'problems_per_gpu': B, 'n_timesteps': N, 'n_iterations': args.iterations, 'n_alpha_parallel': W, 'pipeline': info['pipeline'],
                    'sharding': 'by problem index, %d rank(s), all-gather of {cost,iters,status} only' % world},
         'ms_per_bwd_fwd_pass': round(pass_ms, 4),
         'roofline': roofline,

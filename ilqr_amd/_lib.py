@@ -18,7 +18,7 @@ STATUS_NAMES = {0: 'max_iter', 1: 'optimal', 2: 'low_learning_rate', 3: 'numeric
 # fields of the device-resident workspace (include/ilqr_hip.h)
 F_INIT, F_TARGET, F_PARAMS, F_STATES, F_INPUTS, F_KFF, F_KFB, F_COST, F_DJ, F_ITERS, F_STATUS, F_TRACE, \
     F_LS_ROUNDS, F_ACCEPTS, F_ALPHA, F_STATES_OUT, F_INPUTS_OUT, F_NEW_COST, F_GUESS = range(19)
-KERNEL_NAMES = ('rollout', 'backward', 'linesearch', 'accept', 'ltvlqr', 'forward', 'cost', 'unused')
+KERNEL_NAMES = ('rollout', 'backward', 'linesearch', 'accept', 'ltvlqr', 'forward', 'cost', 'linearize')
 
 
 class IlqrHipError(RuntimeError):
@@ -30,7 +30,7 @@ class Desc(C.Structure):
                 ('n_iterations', C.c_int32), ('n_alpha_parallel', C.c_int32), ('zero_first_state', C.c_int32),
                 ('device', C.c_int32), ('learning_speed', C.c_double), ('low_learning_rate', C.c_double),
                 ('low_expected_reduction', C.c_double), ('armijo_threshold', C.c_double), ('quu_reg', C.c_double),
-                ('target_batched', C.c_int32), ('params_batched', C.c_int32)]
+                ('target_batched', C.c_int32), ('params_batched', C.c_int32), ('pipeline', C.c_int32)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -74,6 +74,7 @@ SIGNATURES = {
     'ilqr_ws_profile': (C.c_int, [_WS, C.c_int32]),
     'ilqr_ws_profile_read': (C.c_int, [_WS, _dp, C.POINTER(C.c_int64)]),
     'ilqr_ws_info': (C.c_int, [_WS, _ip, _ip, C.POINTER(C.c_int64)]),
+    'ilqr_ws_pipeline': (C.c_int, [_WS]),
 }
 
 
@@ -125,7 +126,7 @@ def system_dims(system):
 
 def make_desc(system, N, B, dt, n_iterations=0, n_alpha_parallel=0, zero_first_state=True, device=0,
               target_batched=False, params_batched=False, learning_speed=0.95, low_learning_rate=0.05,
-              low_expected_reduction=1e-3, armijo_threshold=0.1, quu_reg=0.0):
+              low_expected_reduction=1e-3, armijo_threshold=0.1, quu_reg=0.0, pipeline=0):
     d = Desc()
     lib().ilqr_desc_default(C.byref(d))
     d.system_id = SYSTEM_IDS[system] if isinstance(system, str) else int(system)
@@ -143,6 +144,7 @@ def make_desc(system, N, B, dt, n_iterations=0, n_alpha_parallel=0, zero_first_s
     d.low_expected_reduction = float(low_expected_reduction)
     d.armijo_threshold = float(armijo_threshold)
     d.quu_reg = float(quu_reg)
+    d.pipeline = int(pipeline)
     return d
 
 
@@ -238,9 +240,10 @@ class Workspace:
         ms = np.zeros(8)
         cnt = np.zeros(8, dtype=np.int64)
         check(lib().ilqr_ws_profile_read(self._h, dptr(ms), cnt.ctypes.data_as(C.POINTER(C.c_int64))))
-        return {KERNEL_NAMES[i]: (float(ms[i]), int(cnt[i])) for i in range(7)}
+        return {KERNEL_NAMES[i]: (float(ms[i]), int(cnt[i])) for i in range(8)}
 
     def info(self):
         w, t, b = C.c_int32(), C.c_int32(), C.c_int64()
         check(lib().ilqr_ws_info(self._h, C.byref(w), C.byref(t), C.byref(b)))
-        return dict(n_alpha_parallel=w.value, n_trials=t.value, hbm_bytes=b.value)
+        return dict(n_alpha_parallel=w.value, n_trials=t.value, hbm_bytes=b.value,
+                    pipeline={1: 'fused', 2: 'split'}[check(lib().ilqr_ws_pipeline(self._h))])

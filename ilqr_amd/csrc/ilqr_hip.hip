@@ -55,6 +55,8 @@ constexpr int N_KERNEL_IDS = 8;
     struct Sys_##NAME {                                                                                           \
         static constexpr int n = ILQR_DYN_##UP##_N, m = ILQR_DYN_##UP##_M, np = ILQR_DYN_##UP##_NP;               \
         static constexpr int id = ILQR_DYN_##UP##_ID;                                                             \
+        static constexpr const char* A_pat = ilqr_dyn_##NAME##_A_pat;                                             \
+        static constexpr const char* B_pat = ilqr_dyn_##NAME##_B_pat;                                             \
         static __device__ __forceinline__ char a_kind(int i) { return ilqr_dyn_##NAME##_A_pat[i]; }               \
         static __device__ __forceinline__ char b_kind(int i) { return ilqr_dyn_##NAME##_B_pat[i]; }               \
         static __device__ __forceinline__ void f(const double* x, const double* u, double dt, const double* p,   \
@@ -89,6 +91,12 @@ struct KArgs {
     const double* G;       // [tile][N][m][64] initial guess (read by k_rollout only)
     double* KFB;           // [tile][N][m*n][64]
     double* KFF;           // [tile][N][m][64]
+    double* X2;            // split pipeline: accepted trajectory before it is copied back, same layout as X / U
+    double* U2;
+    double* CKPT;          // [problem][segment][n][64 trial slots] line-search checkpoints
+    double* LIN;           // [tile][N][nA_x + nB_x][64] general entries of A_t, B_t
+    int ck;                // checkpoint interval (time steps per segment)
+    int n_seg;             // segments = ceil(N / ck)
     double* XO;            // forward outputs (may alias X/U)
     double* UO;
     const double* INIT;    // [tile][n][64]
@@ -436,6 +444,44 @@ __global__ void __launch_bounds__(64) k_cost(const KArgs a)
     a.cost[tile * TILE + lane] = cost;
 }
 
+// terminal condition of backwards_pass (ilqr.py:67-70): V_x = Q_T (x_N - target); Vxx already holds Q_T
+template <class S>
+__device__ __forceinline__ void terminal_value(const double* xNp, const double (&target)[S::n],
+                                               const double (&Vxx)[S::n * S::n], double (&Vx)[S::n])
+{
+    constexpr int n = S::n;
+    double xN[n], ed[n];
+    load_col<n>(xNp, xN);
+#pragma unroll
+    for (int i = 0; i < n; ++i) ed[i] = xN[i] - target[i];                             // :68
+#pragma unroll
+    for (int i = 0; i < n; ++i) {                                                      // :70
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < n; ++c) s = __builtin_fma(Vxx[i * n + c], ed[c], s);
+        Vx[i] = s;
+    }
+}
+
+// end of backwards_pass for one active problem: expected reductions (:128-130), iteration count, the "optimal"
+// stop test of solve (:175), trace row
+__device__ __forceinline__ void backward_epilogue(const KArgs& a, long long tile, int lane, long long b, double ecr,
+                                                  double ecr_g, double ecr_h, bool ok)
+{
+    double* dj = a.dJ + (size_t)tile * 3 * TILE + lane;
+    dj[0] = ecr; dj[TILE] = ecr_g; dj[2 * TILE] = ecr_h;
+    a.iters[b] += 1;
+    int still = 1;
+    if (!ok) { a.status[b] = ILQR_STATUS_NUMERICAL; still = 0; }
+    else if (fabs(ecr) < a.low_red) { a.status[b] = ILQR_STATUS_OPTIMAL; still = 0; }
+    if (!still) a.active[b] = 0;
+    if (a.trace && a.it < a.n_iter) {
+        double* tr = a.trace + ((size_t)tile * a.n_iter + a.it) * 6 * TILE + lane;
+        tr[0 * TILE] = a.cost[b]; tr[1 * TILE] = ecr; tr[2 * TILE] = ecr_g; tr[3 * TILE] = ecr_h;
+        tr[4 * TILE] = -1.0; tr[5 * TILE] = __builtin_nan("");
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_backward: ilqr.py:64-135.  One lane per problem; V_x, V_xx and the step's Q_* stay in VGPRs.
 // ------------------------------------------------------------------------------------------------
@@ -458,19 +504,7 @@ __global__ void __launch_bounds__(64) k_backward(const KArgs a)
     const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
     double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + lane;
     double* kp = a.KFF + (size_t)tile * a.N * m * TILE + lane;
-    {
-        double xN[n], ed[n];
-        load_col<n>(Xp + (size_t)a.N * n * TILE, xN);
-#pragma unroll
-        for (int i = 0; i < n; ++i) ed[i] = xN[i] - target[i];                         // :68
-#pragma unroll
-        for (int i = 0; i < n; ++i) {                                                  // :70  V_x = Q_T @ ed
-            double s = 0.0;
-#pragma unroll
-            for (int c = 0; c < n; ++c) s = __builtin_fma(Vxx[i * n + c], ed[c], s);
-            Vx[i] = s;
-        }
-    }
+    terminal_value<S>(Xp + (size_t)a.N * n * TILE, target, Vxx, Vx);
     double ecr = 0.0, ecr_g = 0.0, ecr_h = 0.0;
     bool ok = true;
     double x[n], u[m];
@@ -496,43 +530,41 @@ __global__ void __launch_bounds__(64) k_backward(const KArgs a)
 #pragma unroll
         for (int j = 0; j < m; ++j) u[j] = unext[j];
     }
-    if (act) {
-        double* dj = a.dJ + (size_t)tile * 3 * TILE + lane;
-        dj[0] = ecr; dj[TILE] = ecr_g; dj[2 * TILE] = ecr_h;                          // :128-130
-        a.iters[b] += 1;
-        int still = 1;
-        if (!ok) { a.status[b] = ILQR_STATUS_NUMERICAL; still = 0; }
-        else if (fabs(ecr) < a.low_red) { a.status[b] = ILQR_STATUS_OPTIMAL; still = 0; }   // :175
-        if (!still) a.active[b] = 0;
-        if (a.trace && a.it < a.n_iter) {
-            double* tr = a.trace + ((size_t)tile * a.n_iter + a.it) * 6 * TILE + lane;
-            tr[0 * TILE] = a.cost[b]; tr[1 * TILE] = ecr; tr[2 * TILE] = ecr_g; tr[3 * TILE] = ecr_h;
-            tr[4 * TILE] = -1.0; tr[5 * TILE] = __builtin_nan("");
-        }
-    }
+    if (act) backward_epilogue(a, tile, lane, b, ecr, ecr_g, ecr_h, ok);
 }
 
 // ------------------------------------------------------------------------------------------------
-// closed-loop rollout of one lane (ilqr.py:144-157), accumulating compute_cost; optionally storing.
+// closed-loop rollout of one lane over steps [t0, t1) (ilqr.py:144-157), accumulating the input cost of
+// compute_cost; optionally storing the new trajectory (STORE) and the state at every segment boundary (CKPT).
 // ------------------------------------------------------------------------------------------------
-template <class S, bool STORE>
-__device__ __forceinline__ double closed_loop(const KArgs& a, const double* Xp, const double* Up, const double* Kp,
-                                              const double* kp,
-                                              double* XOp, double* UOp, double (&x)[S::n], const double (&p)[S::np],
-                                              const double (&target)[S::n], const double (&Rk)[S::m * S::m],
-                                              const double (&QT)[S::n * S::n], const double alpha)
+template <class S, bool STORE, bool CKPT>
+__device__ __forceinline__ double closed_loop_range(const KArgs& a, const double* Xp, const double* Up, const double* Kp,
+                                                    const double* kp, double* XOp, double* UOp, double* ckp,
+                                                    double (&x)[S::n], const double (&p)[S::np],
+                                                    const double (&Rk)[S::m * S::m], const double alpha, const int t0,
+                                                    const int t1)
 {
     constexpr int n = S::n, m = S::m;
     double cost = 0.0;
     double xb[n], ub[m], K[m * n], kf[m];
-    load_col<n>(Xp, xb); load_col<m>(Up, ub); load_col<m * n>(Kp, K); load_col<m>(kp, kf);
-    for (int t = 0; t < a.N; ++t) {
+    load_col<n>(Xp + (size_t)t0 * n * TILE, xb); load_col<m>(Up + (size_t)t0 * m * TILE, ub);
+    load_col<m * n>(Kp + (size_t)t0 * (m * n) * TILE, K); load_col<m>(kp + (size_t)t0 * m * TILE, kf);
+    int next_ck = CKPT ? a.ck : 0;
+    for (int t = t0; t < t1; ++t) {
         double xb2[n], ub2[m], K2[m * n], kf2[m];                                      // prefetch step t+1 (also makes
-        const int tn = t + 1 < a.N ? t + 1 : t;                                        // the in-place accept safe: the old
+        const int tn = t + 1 < t1 ? t + 1 : t;                                         // the in-place accept safe: the old
         load_col<n>(Xp + (size_t)tn * n * TILE, xb2);                                  // row t+1 is read before it is
         load_col<m>(Up + (size_t)tn * m * TILE, ub2);                                  // overwritten below)
         load_col<m * n>(Kp + (size_t)tn * (m * n) * TILE, K2);
         load_col<m>(kp + (size_t)tn * m * TILE, kf2);
+        if constexpr (CKPT) {
+            if (t == next_ck) {                                                        // state entering segment t / ck
+                double* c = ckp + (size_t)(t / a.ck) * n * TILE;
+#pragma unroll
+                for (int i = 0; i < n; ++i) c[(size_t)i * TILE] = x[i];
+                next_ck += a.ck;
+            }
+        }
         double u[m], xn[n];
 #pragma unroll
         for (int j = 0; j < m; ++j) {
@@ -557,7 +589,18 @@ __device__ __forceinline__ double closed_loop(const KArgs& a, const double* Xp, 
 #pragma unroll
         for (int i = 0; i < m * n; ++i) K[i] = K2[i];
     }
-    cost = cost + terminal_cost<n>(x, target, QT);
+    return cost;
+}
+
+template <class S, bool STORE, bool CKPT = false>
+__device__ __forceinline__ double closed_loop(const KArgs& a, const double* Xp, const double* Up, const double* Kp,
+                                              const double* kp, double* XOp, double* UOp, double (&x)[S::n],
+                                              const double (&p)[S::np], const double (&target)[S::n],
+                                              const double (&Rk)[S::m * S::m], const double (&QT)[S::n * S::n],
+                                              const double alpha, double* ckp = nullptr)
+{
+    double cost = closed_loop_range<S, STORE, CKPT>(a, Xp, Up, Kp, kp, XOp, UOp, ckp, x, p, Rk, alpha, 0, a.N);
+    cost = cost + terminal_cost<S::n>(x, target, QT);
     return cost;
 }
 
@@ -566,7 +609,7 @@ __device__ __forceinline__ double closed_loop(const KArgs& a, const double* Xp, 
 // (64/W problems per wave); the accepted trial is the FIRST j whose Armijo ratio passes (:193), found with a
 // ballot over the lane group -- not the lowest cost.  Rounds of W trials repeat until accepted or exhausted.
 // ------------------------------------------------------------------------------------------------
-template <class S, int W>
+template <class S, int W, bool CKPT>
 __global__ void __launch_bounds__(256) k_linesearch(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
@@ -606,7 +649,8 @@ __global__ void __launch_bounds__(256) k_linesearch(const KArgs a)
             double x[n];
 #pragma unroll
             for (int i = 0; i < n; ++i) x[i] = x0[i];
-            c = closed_loop<S, false>(a, Xp, Up, Kp, kp, nullptr, nullptr, x, p, target, Rk, QT, alpha);
+            double* ckp = CKPT ? a.CKPT + (size_t)b * a.n_seg * n * TILE + j : nullptr;
+            c = closed_loop<S, false, CKPT>(a, Xp, Up, Kp, kp, nullptr, nullptr, x, p, target, Rk, QT, alpha, ckp);
             const double cost_difference = cur_cost - c;                               // :191
             const double expected = alpha * dg + (alpha * alpha) * dh;                 // :192
             okj = (cost_difference / expected) > a.armijo_thr;                         // :193 (NaN -> false)
@@ -684,6 +728,194 @@ __global__ void __launch_bounds__(64) k_forward(const KArgs a)
             a.new_cost[b] = c;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split pipeline (small batches: the horizon-sequential kernels would leave most SIMDs idle).
+//   k_accept_par : the accept step (:194-207) in parallel over (tile, segment): each lane restarts the winning
+//                  trial from the checkpoint the line search stored at its segment boundary and re-rolls ck steps
+//                  into X2/U2 (same arithmetic, same order => same bits as the trial itself).
+//   k_linearize  : parallel over (tile, block of time steps): evaluates A_t, B_t (ilqr.py:96-97) at the stored
+//                  trajectory and keeps their general entries in LIN; with COPY it first moves the accepted
+//                  trajectory X2/U2 -> X/U.
+//   k_riccati    : the horizon-sequential part of backwards_pass (:99-125) reading LIN instead of calling A(), B().
+// ------------------------------------------------------------------------------------------------
+template <class S>
+__global__ void __launch_bounds__(64) k_accept_par(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m, np = S::np;
+    const long long tile = blockIdx.x / a.n_seg;
+    const int seg = (int)(blockIdx.x % a.n_seg);
+    const int lane = threadIdx.x;
+    const long long b = tile * TILE + lane;
+    const bool act = a.active[b] != 0;
+    const int accj = act ? a.acc_j[b] : -1;
+    const bool run = act && accj >= 0;
+    if (__ballot(act) == 0ull) return;
+    if (run) {
+        const double alpha = a.alphas[accj];
+        double x[n], p[np], Rk[m * m];
+        load_col<np>(a.PARAMS + (size_t)tile * np * TILE + lane, p);
+        load_uniform<m * m>(a.WTS + n * n, Rk);
+        if (seg == 0) {
+            load_col<n>(a.INIT + (size_t)tile * n * TILE + lane, x);
+        } else {
+            const double* c = a.CKPT + ((size_t)b * a.n_seg + seg) * n * TILE + accj;
+#pragma unroll
+            for (int i = 0; i < n; ++i) x[i] = c[(size_t)i * TILE];
+        }
+        const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
+        const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+        const double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + lane;
+        const double* kp = a.KFF + (size_t)tile * a.N * m * TILE + lane;
+        double* XOp = a.X2 + (size_t)tile * a.state_rows * n * TILE + lane;
+        double* UOp = a.U2 + (size_t)tile * a.N * m * TILE + lane;
+        const int t0 = seg * a.ck;
+        const int t1 = t0 + a.ck < a.N ? t0 + a.ck : a.N;
+        (void)closed_loop_range<S, true, false>(a, Xp, Up, Kp, kp, XOp, UOp, nullptr, x, p, Rk, alpha, t0, t1);
+    }
+    if (seg == 0 && act) {                                                             // per-problem bookkeeping, once
+        if (accj < 0) { a.status[b] = ILQR_STATUS_LOW_LR; a.active[b] = 0; }           // :204-207
+        else {
+            const double nc = a.new_cost[b];
+            a.cost[b] = nc;                                                            // :197
+            a.accepts[b] += 1;
+            if (a.trace && a.it < a.n_iter) {
+                double* tr = a.trace + ((size_t)tile * a.n_iter + a.it) * 6 * TILE + lane;
+                tr[4 * TILE] = (double)accj; tr[5 * TILE] = nc;
+            }
+        }
+    }
+}
+
+template <class S>
+struct Lin {
+    static constexpr int count_x(const char* pat, int len)
+    {
+        int c = 0;
+        for (int i = 0; i < len; ++i) c += pat[i] == 'x';
+        return c;
+    }
+    static constexpr int nA = count_x(S::A_pat, S::n * S::n);
+    static constexpr int nB = count_x(S::B_pat, S::n * S::m);
+    static constexpr int n_lin = nA + nB;
+};
+
+constexpr int LIN_TS = 8;   // time steps per wave in k_linearize
+
+template <class S, bool COPY>
+__global__ void __launch_bounds__(64) k_linearize(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m, np = S::np;
+    const int chunks = (a.N + LIN_TS - 1) / LIN_TS;
+    const long long tile = blockIdx.x / chunks;
+    const int chunk = (int)(blockIdx.x % chunks);
+    const int lane = threadIdx.x;
+    const long long b = tile * TILE + lane;
+    const bool act = a.active[b] != 0;
+    const bool run = COPY ? (act && a.acc_j[b] >= 0) : act;
+    if (__ballot(run) == 0ull) return;
+    if (!run) return;
+    double p[np];
+    load_col<np>(a.PARAMS + (size_t)tile * np * TILE + lane, p);
+    double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
+    double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+    const double* X2p = a.X2 + (size_t)tile * a.state_rows * n * TILE + lane;
+    const double* U2p = a.U2 + (size_t)tile * a.N * m * TILE + lane;
+    double* Lp = a.LIN + (size_t)tile * a.N * Lin<S>::n_lin * TILE + lane;
+    const int t0 = chunk * LIN_TS;
+    const int t1 = t0 + LIN_TS < a.N ? t0 + LIN_TS : a.N;
+    for (int t = t0; t < t1; ++t) {
+        double x[n], u[m];
+        if constexpr (COPY) {
+            if (t == 0) load_col<n>(Xp, x);                 // row 0 never changes (zero or init_state)
+            else { load_col<n>(X2p + (size_t)t * n * TILE, x); store_col<n>(Xp + (size_t)t * n * TILE, x); }
+            load_col<m>(U2p + (size_t)t * m * TILE, u);
+            store_col<m>(Up + (size_t)t * m * TILE, u);
+            if (t == a.N - 1) {
+                double xN[n];
+                load_col<n>(X2p + (size_t)a.N * n * TILE, xN);
+                store_col<n>(Xp + (size_t)a.N * n * TILE, xN);
+            }
+        } else {
+            load_col<n>(Xp + (size_t)t * n * TILE, x);
+            load_col<m>(Up + (size_t)t * m * TILE, u);
+        }
+        double A[n * n], Bm[n * m];
+        S::A(x, u, a.dt, p, A);                                                        // :96
+        S::B(x, u, a.dt, p, Bm);                                                       // :97
+        double* l = Lp + (size_t)t * Lin<S>::n_lin * TILE;
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < n * n; ++i) if (S::a_kind(i) == 'x') { l[(size_t)e * TILE] = A[i]; ++e; }
+#pragma unroll
+        for (int i = 0; i < n * m; ++i) if (S::b_kind(i) == 'x') { l[(size_t)e * TILE] = Bm[i]; ++e; }
+    }
+}
+
+template <class S>
+__device__ __forceinline__ void load_lin(const double* l, double (&A)[S::n * S::n], double (&Bm)[S::n * S::m])
+{
+    constexpr int n = S::n, m = S::m;
+    int e = 0;
+#pragma unroll
+    for (int i = 0; i < n * n; ++i) {
+        const char kd = S::a_kind(i);
+        if (kd == 'x') { A[i] = l[(size_t)e * TILE]; ++e; } else A[i] = kd == '1' ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < n * m; ++i) {
+        const char kd = S::b_kind(i);
+        if (kd == 'x') { Bm[i] = l[(size_t)e * TILE]; ++e; } else Bm[i] = kd == '1' ? 1.0 : 0.0;
+    }
+}
+
+template <class S>
+__global__ void __launch_bounds__(64) k_riccati(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m;
+    const long long tile = blockIdx.x;
+    const int lane = threadIdx.x;
+    const long long b = tile * TILE + lane;
+    const bool act = a.active[b] != 0;
+    if (__ballot(act) == 0ull) return;
+    double target[n], Qk[n * n], Rk[m * m], Vx[n], Vxx[n * n];
+    load_col<n>(a.TARGET + (size_t)tile * n * TILE + lane, target);
+    load_uniform<n * n>(a.WTS, Qk);
+    load_uniform<m * m>(a.WTS + n * n, Rk);
+    load_uniform<n * n>(a.WTS + n * n + m * m, Vxx);                                   // :67
+    const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
+    const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+    const double* Lp = a.LIN + (size_t)tile * a.N * Lin<S>::n_lin * TILE + lane;
+    double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + lane;
+    double* kp = a.KFF + (size_t)tile * a.N * m * TILE + lane;
+    terminal_value<S>(Xp + (size_t)a.N * n * TILE, target, Vxx, Vx);
+    double ecr = 0.0, ecr_g = 0.0, ecr_h = 0.0;
+    bool ok = true;
+    double A[n * n], Bm[n * m], u[m];
+    load_lin<S>(Lp + (size_t)(a.N - 1) * Lin<S>::n_lin * TILE, A, Bm);
+    load_col<m>(Up + (size_t)(a.N - 1) * m * TILE, u);
+    for (int t = a.N - 1; t >= 0; --t) {                                               // :82
+        double A2[n * n], B2[n * m], u2[m];                                            // prefetch step t-1
+        const int tp = t > 0 ? t - 1 : 0;
+        load_lin<S>(Lp + (size_t)tp * Lin<S>::n_lin * TILE, A2, B2);
+        load_col<m>(Up + (size_t)tp * m * TILE, u2);
+        double k[m], K[m * n], g, h;
+        ok = Riccati<S>::step(A, Bm, u, Qk, Rk, a.quu_reg, Vx, Vxx, k, K, g, h) && ok;
+        if (act) {
+            store_col<m>(kp + (size_t)t * m * TILE, k);                                // :111
+            store_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K);                      // :112
+        }
+        const double cur = g + h;                                                      // :117
+        ecr_g += g; ecr_h += h; ecr += cur;                                            // :119-121
+#pragma unroll
+        for (int i = 0; i < n * n; ++i) A[i] = A2[i];
+#pragma unroll
+        for (int i = 0; i < n * m; ++i) Bm[i] = B2[i];
+#pragma unroll
+        for (int j = 0; j < m; ++j) u[j] = u2[j];
+    }
+    if (act) backward_epilogue(a, tile, lane, b, ecr, ecr_g, ecr_h, ok);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -897,7 +1129,9 @@ int fail(int code, const char* fmt, ...)
         if (e_ != hipSuccess) return fail(-100 - (int)e_, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-enum { KID_ROLLOUT = 0, KID_BACKWARD = 1, KID_LINESEARCH = 2, KID_ACCEPT = 3, KID_LTVLQR = 4, KID_FORWARD = 5, KID_COST = 6 };
+enum { KID_ROLLOUT = 0, KID_BACKWARD = 1, KID_LINESEARCH = 2, KID_ACCEPT = 3, KID_LTVLQR = 4, KID_FORWARD = 5, KID_COST = 6,
+       KID_LINEARIZE = 7 };
+constexpr int CKPT_INTERVAL = 64;   // time steps between line-search checkpoints (split pipeline)
 
 }  // namespace
 
@@ -906,6 +1140,8 @@ struct ilqr_ws {
     int n, m, np, N, W, n_trials, want_trace;
     long long B, Bpad, tiles;
     hipStream_t stream;
+    double *X2, *U2, *CKPT, *LIN;
+    int split, ck, n_seg, n_lin;
     double *X, *U, *G, *KFB, *KFF, *XO, *UO, *INIT, *TARGET, *PARAMS, *WTS, *alphas, *alpha_pp, *cost, *new_cost, *dJ, *trace;
     int *active, *iters, *status, *acc_j, *ls_rounds, *accepts;
     void* staging;
@@ -929,6 +1165,7 @@ KArgs make_args(ilqr_ws* ws, int it)
     a.n_trials = ws->n_trials; a.state_rows = ws->state_rows; a.n_tiles = ws->tiles;
     a.dt = ws->d.dt; a.low_red = ws->d.low_expected_reduction; a.armijo_thr = ws->d.armijo_threshold;
     a.quu_reg = ws->d.quu_reg;
+    a.X2 = ws->X2; a.U2 = ws->U2; a.CKPT = ws->CKPT; a.LIN = ws->LIN; a.ck = ws->ck; a.n_seg = ws->n_seg;
     a.X = ws->X; a.U = ws->U; a.G = ws->G; a.KFB = ws->KFB; a.KFF = ws->KFF; a.XO = ws->X; a.UO = ws->U;
     a.INIT = ws->INIT; a.TARGET = ws->TARGET; a.PARAMS = ws->PARAMS; a.WTS = ws->WTS; a.alphas = ws->alphas;
     a.alpha_pp = ws->alpha_pp; a.cost = ws->cost; a.new_cost = ws->new_cost; a.dJ = ws->dJ; a.active = ws->active;
@@ -975,12 +1212,13 @@ int check_launch(const char* what)
 }
 
 template <class S, int W>
-void launch_ls(ilqr_ws* ws, const KArgs& a)
+void launch_ls(ilqr_ws* ws, const KArgs& a, bool ckpt)
 {
     const long long waves = ws->Bpad * W / TILE;
     const int wpb = 4;   // 256 threads
     const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
-    hipLaunchKernelGGL((k_linesearch<S, W>), dim3(grid), dim3(256), 0, ws->stream, a);
+    if (ckpt) hipLaunchKernelGGL((k_linesearch<S, W, true>), dim3(grid), dim3(256), 0, ws->stream, a);
+    else hipLaunchKernelGGL((k_linesearch<S, W, false>), dim3(grid), dim3(256), 0, ws->stream, a);
 }
 
 int set_device(const ilqr_ws* ws)
@@ -1133,6 +1371,28 @@ int run_pass(ilqr_ws* ws, int kid, int it, const char* name, F&& launch)
     });
 }
 
+int ws_linearize(ilqr_ws* ws, bool copy)
+{
+    const int chunks = (ws->N + LIN_TS - 1) / LIN_TS;
+    const unsigned grid = (unsigned)(ws->tiles * chunks);
+    return run_pass(ws, KID_LINEARIZE, 0, "k_linearize", [&](auto S, const KArgs& a) {
+        if (copy) hipLaunchKernelGGL((k_linearize<decltype(S), true>), dim3(grid), dim3(64), 0, ws->stream, a);
+        else hipLaunchKernelGGL((k_linearize<decltype(S), false>), dim3(grid), dim3(64), 0, ws->stream, a);
+    });
+}
+int ws_riccati(ilqr_ws* ws, int it)
+{
+    return run_pass(ws, KID_BACKWARD, it, "k_riccati", [&](auto S, const KArgs& a) {
+        hipLaunchKernelGGL(k_riccati<decltype(S)>, dim3((unsigned)ws->tiles), dim3(64), 0, ws->stream, a);
+    });
+}
+int ws_accept_par(ilqr_ws* ws, int it)
+{
+    return run_pass(ws, KID_ACCEPT, it, "k_accept_par", [&](auto S, const KArgs& a) {
+        hipLaunchKernelGGL(k_accept_par<decltype(S)>, dim3((unsigned)(ws->tiles * ws->n_seg)), dim3(64), 0, ws->stream, a);
+    });
+}
+
 int validate_desc(const ilqr_desc* d)
 {
     if (!d) return fail(-1, "null descriptor");
@@ -1142,6 +1402,7 @@ int validate_desc(const ilqr_desc* d)
     if (d->n_iterations < 0) return fail(-1, "n_iterations must be >= 0");
     const int w = d->n_alpha_parallel;
     if (w != 0 && (w < 1 || w > 64 || (w & (w - 1)) != 0)) return fail(-1, "n_alpha_parallel must be 0 or a power of two <= 64");
+    if (d->pipeline < 0 || d->pipeline > 2) return fail(-1, "pipeline must be 0 (auto), 1 (fused) or 2 (split)");
     if (!(d->learning_speed > 0.0 && d->learning_speed < 1.0)) return fail(-1, "learning_speed must be in (0,1)");
     if (!(d->low_learning_rate > 0.0 && d->low_learning_rate < 1.0)) return fail(-1, "low_learning_rate must be in (0,1)");
     return 0;
@@ -1165,6 +1426,7 @@ void ilqr_desc_default(ilqr_desc* d)
     d->low_expected_reduction = 1e-3;
     d->armijo_threshold = 0.1;
     d->quu_reg = 0.0;
+    d->pipeline = 0;
 }
 
 int ilqr_abi_version(void) { return ILQR_ABI_VERSION; }
@@ -1271,6 +1533,14 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
         while (W < 64 && ws->Bpad * (long long)(W * 2) / TILE <= 4096) W *= 2;
     }
     ws->W = W;
+    // pipeline: with few tiles the horizon-sequential kernels occupy one wave per tile and leave most of the 1024 SIMDs
+    // idle, so the parallel parts (accept re-roll, Jacobians) are split off; large batches fill the chip either way and
+    // keep the fused kernels (no LIN / checkpoint traffic).
+    ws->split = d->pipeline == 2 || (d->pipeline == 0 && ws->tiles < 1024);
+    if (d->n_iterations == 0) ws->split = 0;
+    ws->ck = CKPT_INTERVAL;
+    ws->n_seg = (ws->N + ws->ck - 1) / ws->ck;
+    ws->n_lin = with_system(d->system_id, [&](auto S) { return Lin<decltype(S)>::n_lin; });
     const size_t Bp = (size_t)ws->Bpad, n = ws->n, m = ws->m, np = ws->np, N = ws->N;
     struct { void** p; size_t bytes; } allocs[] = {
         {(void**)&ws->X, Bp * (N + 1) * n * 8}, {(void**)&ws->U, Bp * N * m * 8}, {(void**)&ws->G, Bp * N * m * 8}, {(void**)&ws->KFB, Bp * N * m * n * 8},
@@ -1280,6 +1550,9 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
         {(void**)&ws->active, Bp * 4}, {(void**)&ws->iters, Bp * 4}, {(void**)&ws->status, Bp * 4}, {(void**)&ws->acc_j, Bp * 4},
         {(void**)&ws->ls_rounds, Bp * 4}, {(void**)&ws->accepts, Bp * 4},
         {(void**)&ws->trace, ws->want_trace ? Bp * (size_t)d->n_iterations * 6 * 8 : 0},
+        {(void**)&ws->X2, ws->split ? Bp * (N + 1) * n * 8 : 0}, {(void**)&ws->U2, ws->split ? Bp * N * m * 8 : 0},
+        {(void**)&ws->CKPT, ws->split ? Bp * (size_t)ws->n_seg * n * TILE * 8 : 0},
+        {(void**)&ws->LIN, ws->split ? Bp * N * (size_t)ws->n_lin * 8 : 0},
     };
     ws->hbm_bytes = 0;
     for (auto& al : allocs) {
@@ -1319,7 +1592,7 @@ int ilqr_ws_destroy(ilqr_ws* ws)
     (void)hipSetDevice(ws->d.device);
     if (ws->stream) (void)hipStreamSynchronize(ws->stream);
     for (auto& ev : ws->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    void* ptrs[] = {ws->X, ws->U, ws->G, ws->KFB, ws->KFF, ws->XO, ws->UO, ws->INIT, ws->TARGET, ws->PARAMS, ws->WTS, ws->alphas,
+    void* ptrs[] = {ws->X2, ws->U2, ws->CKPT, ws->LIN, ws->X, ws->U, ws->G, ws->KFB, ws->KFF, ws->XO, ws->UO, ws->INIT, ws->TARGET, ws->PARAMS, ws->WTS, ws->alphas,
                     ws->alpha_pp, ws->cost, ws->new_cost, ws->dJ, ws->trace, ws->active, ws->iters, ws->status, ws->acc_j,
                     ws->ls_rounds, ws->accepts, ws->staging};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1407,13 +1680,13 @@ int ilqr_ws_linesearch(ilqr_ws* ws)
     return run_pass(ws, KID_LINESEARCH, 0, "k_linesearch", [&](auto S, const KArgs& a) {
         using T = decltype(S);
         switch (ws->W) {
-            case 1: launch_ls<T, 1>(ws, a); break;
-            case 2: launch_ls<T, 2>(ws, a); break;
-            case 4: launch_ls<T, 4>(ws, a); break;
-            case 8: launch_ls<T, 8>(ws, a); break;
-            case 16: launch_ls<T, 16>(ws, a); break;
-            case 32: launch_ls<T, 32>(ws, a); break;
-            default: launch_ls<T, 64>(ws, a); break;
+            case 1: launch_ls<T, 1>(ws, a, ws->split != 0); break;
+            case 2: launch_ls<T, 2>(ws, a, ws->split != 0); break;
+            case 4: launch_ls<T, 4>(ws, a, ws->split != 0); break;
+            case 8: launch_ls<T, 8>(ws, a, ws->split != 0); break;
+            case 16: launch_ls<T, 16>(ws, a, ws->split != 0); break;
+            case 32: launch_ls<T, 32>(ws, a, ws->split != 0); break;
+            default: launch_ls<T, 64>(ws, a, ws->split != 0); break;
         }
     });
 }
@@ -1448,6 +1721,16 @@ int ilqr_ws_solve(ilqr_ws* ws)
     int rc;
     if ((rc = ilqr_ws_reset(ws))) return rc;
     if ((rc = ilqr_ws_rollout(ws))) return rc;                 // ilqr.py:162-164
+    if (ws->split) {
+        if ((rc = ws_linearize(ws, false))) return rc;         // A_t, B_t of the initial trajectory (:96-97)
+        for (int it = 0; it < ws->d.n_iterations; ++it) {      // :170
+            if ((rc = ws_riccati(ws, it))) return rc;          // :99-135, :173-179
+            if ((rc = ilqr_ws_linesearch(ws))) return rc;      // :180-202 (+ checkpoints)
+            if ((rc = ws_accept_par(ws, it))) return rc;       // :194-207, segments in parallel
+            if ((rc = ws_linearize(ws, true))) return rc;      // copy the accepted trajectory back, A_t, B_t for the next pass
+        }
+        return 0;
+    }
     for (int it = 0; it < ws->d.n_iterations; ++it) {          // :170
         if ((rc = ilqr_ws_backward(ws, it))) return rc;        // :173-179
         if ((rc = ilqr_ws_linesearch(ws))) return rc;          // :180-202
@@ -1499,6 +1782,12 @@ int ilqr_ws_info(ilqr_ws* ws, int32_t* W, int32_t* n_trials, int64_t* hbm_bytes)
     if (n_trials) *n_trials = ws->n_trials;
     if (hbm_bytes) *hbm_bytes = (int64_t)ws->hbm_bytes;
     return 0;
+}
+
+int ilqr_ws_pipeline(ilqr_ws* ws)
+{
+    if (!ws) return fail(-1, "null workspace");
+    return ws->split ? 2 : 1;
 }
 
 // ------------------------------------------------------------------------------ one-shot host API

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ILQR_ABI_VERSION 1
+#define ILQR_ABI_VERSION 2
 
 /* systems compiled into the library (sympy-generated __device__ dynamics, ilqr_amd/csrc/dynamics/) */
 enum { ILQR_SYS_PENDULUM = 0, ILQR_SYS_ACROBOT = 1, ILQR_SYS_CARTPOLE = 2, ILQR_SYS_QUADCOPTER = 3 };
@@ -55,6 +55,9 @@ typedef struct ilqr_desc {
     double quu_reg;               /* added to diag(Q_uu); 0 = reference behaviour (ilqr.py:106 has none) */
     int32_t target_batched;       /* 0: target_state is (n,) shared; 1: (B,n) */
     int32_t params_batched;       /* 0: parameters is (P,) shared; 1: (B,P) */
+    int32_t pipeline;             /* kernel schedule of solve(): 0 auto, 1 fused (backward | line search | accept),
+                                     2 split (Jacobians and the accept re-roll in parallel over time; small batches).
+                                     Results are bit-identical for both. */
 } ilqr_desc;
 
 void ilqr_desc_default(ilqr_desc* d);
@@ -151,10 +154,12 @@ int ilqr_ws_solve(ilqr_ws* ws);            /* ilqr.py:159-211: reset, rollout, n
 int ilqr_ws_ltvlqr(ilqr_ws* ws);           /* ltvlqr.py:3-28 on STATES/INPUTS -> KFB */
 int ilqr_ws_sync(ilqr_ws* ws);
 /* kernel timing with HIP events on the workspace stream.  kernel ids: 0 rollout, 1 backward, 2 linesearch, 3 accept,
- * 4 ltvlqr, 5 forward, 6 cost.  ms[i] = summed duration, launches[i] = count since the last enable. */
+ * 4 ltvlqr, 5 forward, 6 cost, 7 linearize.  In the split pipeline backward = k_riccati, accept = k_accept_par.
+ * ms[i] = summed duration, launches[i] = count since the last enable. */
 int ilqr_ws_profile(ilqr_ws* ws, int32_t enable);
 int ilqr_ws_profile_read(ilqr_ws* ws, double* ms /*8*/, int64_t* launches /*8*/);
 int ilqr_ws_info(ilqr_ws* ws, int32_t* n_alpha_parallel, int32_t* n_trials, int64_t* hbm_bytes);
+int ilqr_ws_pipeline(ilqr_ws* ws);         /* 1 fused, 2 split: the schedule solve() uses for this workspace */
 
 #ifdef __cplusplus
 }

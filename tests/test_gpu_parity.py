@@ -27,13 +27,13 @@ def dyn(amd, system):
     return getattr(amd, 'symbolic_dynamics_' + system)()
 
 
-def make_solver(amd, system, g, n_alpha_parallel=0, verbose=False, **over):
+def make_solver(amd, system, g, n_alpha_parallel=0, verbose=False, pipeline=0, **over):
     f, A, B = dyn(amd, system)
     c = {k: g[k] for k in ('init', 'target', 'guess', 'Qk', 'Rk', 'QT', 'params')}
     c.update(dt=float(g['dt']), start=float(g['start']), end=float(g['end']), n_iterations=int(g['n_iterations']))
     c.update(over)
     return amd.ilqr(c['init'], c['target'], c['guess'], c['dt'], c['start'], c['end'], f, A, B, c['Qk'], c['Rk'], c['QT'],
-                    c['params'], c['n_iterations'], verbose=verbose, n_alpha_parallel=n_alpha_parallel)
+                    c['params'], c['n_iterations'], verbose=verbose, n_alpha_parallel=n_alpha_parallel, pipeline=pipeline)
 
 
 # ------------------------------------------------------------------------------------------ dynamics
@@ -232,6 +232,29 @@ def test_alpha_width_does_not_change_results(amd):
     for o in outs[1:]:
         for a, b in zip(o, outs[0]):
             assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize('system', SYSTEMS)
+def test_fused_and_split_pipelines_agree_bitwise(amd, system):
+    """the split schedule (parallel accept from checkpoints, Jacobians precomputed in parallel) is a re-scheduling of
+    the same arithmetic: every output and the whole trace are bit-identical to the fused schedule"""
+    g = golden(system + '_batch')
+    outs = []
+    for pipeline in (1, 2):
+        s = make_solver(amd, system, g, pipeline=pipeline, n_iterations=5)
+        outs.append(s.solve() + (s.trace_.copy(), s.status_.copy(), s.iterations_.copy()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize('pipeline', [1, 2])
+def test_acrobot_example_both_pipelines(amd, pipeline):
+    """N = 3000 is not a multiple of the 64-step checkpoint interval: last segment is short"""
+    g = golden('acrobot_solve')
+    s = make_solver(amd, 'acrobot', g, pipeline=pipeline)
+    out = s.solve()
+    assert np.array_equal(s.trace_[:int(g['iters']), 4], g['trace'][:, 4])
+    check_solve(out, g)
 
 
 def test_ltvlqr_vs_oracle_batch(amd, oracle):
