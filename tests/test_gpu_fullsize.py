@@ -1,0 +1,188 @@
+"""GPU tests at BASELINE.json's full per-GPU sizes (configs[1..4]).
+
+The CPU oracle cannot solve 10^5 problems in seconds, so at these sizes parity is checked through
+  * a seeded SAMPLE of problems compared with the oracle (1e-8 relative, same bar as everywhere),
+  * the reference's own example embedded as problem 0 (golden fixtures),
+  * size-independent properties: the stored trajectory is a fixed point of the dynamics (x_{t+1} == f(x_t,u_t), bitwise,
+    re-evaluated by the dynamics kernel), the reported cost equals compute_cost of the stored trajectory, accepted line
+    searches never increase the cost, duplicated problems give bit-identical results wherever they sit in the batch,
+    every status/iteration count is consistent with the trace.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import ilqr_amd
+    ilqr_amd._lib.require_gpu()
+    return ilqr_amd
+
+
+def solve_ws(amd, system, cfg, init, guess, target, n_iterations, W=0, target_batched=False, pipeline=0):
+    from ilqr_amd import _lib
+    B, N = guess.shape[0], guess.shape[1]
+    ws = amd.Workspace(system, N, B, float(cfg['dt']), want_trace=True, n_iterations=n_iterations, n_alpha_parallel=W,
+                       target_batched=target_batched, pipeline=pipeline)
+    ws.set_weights(cfg['Qk'], cfg['Rk'], cfg['QT'])
+    ws.upload(_lib.F_PARAMS, cfg['params'])
+    ws.upload(_lib.F_INIT, init)
+    ws.upload(_lib.F_TARGET, target)
+    ws.upload(_lib.F_GUESS, guess)
+    ws.solve()
+    ws.sync()
+    return ws
+
+
+def check_properties(amd, ws, system, cfg, init, sample):
+    """size-independent invariants of a finished solve, on the whole batch (cheap ones) and on `sample` (trajectory ones)"""
+    from ilqr_amd import _lib
+    trace = ws.download(_lib.F_TRACE)
+    status = ws.download(_lib.F_STATUS)
+    iters = ws.download(_lib.F_ITERS)
+    cost = ws.download(_lib.F_COST)
+    B, n_it = trace.shape[0], trace.shape[1]
+    assert np.isfinite(cost).all()
+    assert set(np.unique(status)) <= {0, 1, 2}
+    ran = np.isfinite(trace[:, :, 1])
+    assert np.array_equal(ran.sum(1), iters)                               # one trace row per backward pass
+    assert np.all(ran[:, 0]) and np.all(ran[:, :-1] >= ran[:, 1:])         # rows are a prefix
+    accepted = trace[:, :, 4] >= 0
+    # an accepted trial passed Armijo: (J - J_new) / (a g + a^2 h) > 0.1, so with a positive model decrease the cost drops
+    dec = trace[:, :, 0] - trace[:, :, 5]
+    alpha = 0.95 ** np.maximum(trace[:, :, 4], 0)
+    model = alpha * trace[:, :, 2] + alpha ** 2 * trace[:, :, 3]
+    assert np.all((dec / model > 0.1 - 1e-9)[accepted])
+    # status vs trace: max-iter problems ran every iteration and accepted in the last one; low-lr ones did not accept last
+    last = np.maximum(iters - 1, 0)
+    last_acc = accepted[np.arange(B), last]
+    assert np.all(iters[status == 0] == n_it) and np.all(last_acc[status == 0])
+    assert not np.any(last_acc[status == 2])
+    assert np.all(np.abs(trace[np.arange(B), last, 1])[status == 1] < 1e-3)
+    # the final cost is the cost after the last accepted trial (or the rollout cost)
+    last_cost = np.where(last_acc, trace[np.arange(B), last, 5], trace[np.arange(B), last, 0])
+    assert np.array_equal(cost, last_cost)
+    # compute_cost of the stored trajectory reproduces it (same kernel arithmetic => tight)
+    ws.cost()
+    ws.sync()
+    recomputed = ws.download(_lib.F_COST)
+    assert np.max(np.abs(recomputed - cost) / np.abs(cost)) < 1e-12
+    # the stored trajectory obeys the dynamics bit for bit
+    states = ws.download(_lib.F_STATES)[sample]
+    inputs = ws.download(_lib.F_INPUTS)[sample]
+    f = getattr(amd, 'symbolic_dynamics_' + system)()[0]
+    x_prev = states[:, :-1].copy()
+    x_prev[:, 0] = init[sample]                                            # row 0 is stored as zero (reference quirk)
+    assert np.all(states[:, 0] == 0.0)
+    nxt = f.batch(x_prev.reshape(-1, states.shape[2]), inputs.reshape(-1, inputs.shape[2]), float(cfg['dt']), cfg['params'])
+    assert np.array_equal(nxt.reshape(states[:, 1:].shape), states[:, 1:])
+    return trace, status, iters, cost
+
+
+def compare_sample_with_oracle(oracle, system, cfg, init, guess, target, ws, sample, n_check):
+    """trace of the first n_check iterations of the sampled problems vs the CPU oracle"""
+    from ilqr_amd import _lib
+    trace = ws.download(_lib.F_TRACE)
+    for b in sample:
+        tg = target[b] if np.ndim(target) == 2 else target
+        r = oracle.solve(system, init[b], tg, guess[b], cfg['Qk'], cfg['Rk'], cfg['QT'], float(cfg['dt']), cfg['params'], n_check)
+        k = min(n_check, int(r['iters']))
+        assert np.array_equal(trace[b, :k, 4], r['trace'][:k, 4]), b
+        assert rel_err(trace[b, :k, 0], r['trace'][:k, 0]) < TOL, b
+        assert rel_err(trace[b, :k, 1], r['trace'][:k, 1]) < TOL, b
+
+
+def test_c2_acrobot_4096(amd, oracle):
+    """configs[1]: acrobot swing-up, 4096 random initial states, N=3000, 10 iterations (the bench workload)"""
+    import bench
+    cfg = bench.acrobot_c2(4096, seed=0)
+    init, guess = cfg['init'], cfg['guess']
+    init[4000], guess[4000] = init[7], guess[7]                            # a duplicate far away in another tile
+    ws = solve_ws(amd, 'acrobot', cfg, init, guess, cfg['target'], 10)
+    assert ws.info()['pipeline'] == 'split'
+    sample = np.array([0, 7, 63, 64, 2049, 4000, 4095])
+    trace, status, iters, cost = check_properties(amd, ws, 'acrobot', cfg, init, sample)
+    g = golden('acrobot_solve')                                            # problem 0 is the reference's example
+    assert np.array_equal(trace[0, :10, 4], g['trace'][:10, 4])
+    assert rel_err(trace[0, :10, 0], g['trace'][:10, 0]) < TOL
+    from ilqr_amd import _lib
+    states = ws.download(_lib.F_STATES)
+    K = ws.download(_lib.F_KFB)
+    assert np.array_equal(states[7], states[4000]) and np.array_equal(K[7], K[4000]) and cost[7] == cost[4000]
+    compare_sample_with_oracle(oracle, 'acrobot', cfg, init, guess, cfg['target'], ws, [0, 63, 2049], 4)
+    # the same problems solved alone (other batch size, fused schedule, other alpha width): identical bits
+    sub = np.array([7, 2049, 4095])
+    ws2 = solve_ws(amd, 'acrobot', cfg, init[sub], guess[sub], cfg['target'], 10, W=8, pipeline=1)
+    assert np.array_equal(ws2.download(_lib.F_STATES), states[sub])
+    assert np.array_equal(ws2.download(_lib.F_TRACE), trace[sub], equal_nan=True)
+
+
+def test_c3_ltvlqr_65536(amd, oracle):
+    """configs[2]: ltvlqr gain schedules for 65 536 perturbed copies of the reference's acrobot_swingup_*.csv trajectory"""
+    from ilqr_amd import _lib
+    csv, g = golden('acrobot_csv'), golden('acrobot_ltvlqr')
+    B, N, D = 65536, 3000, 512
+    rng = np.random.default_rng(1)
+    ds = 1e-2 * rng.standard_normal((D, N + 1, 4))
+    du = 1e-1 * rng.standard_normal((D, N, 1))
+    ds[0] = 0.0; du[0] = 0.0                                               # problem 0: the unperturbed CSV
+    scale = (1.0 + np.arange(B // D) * 1e-3)[:, None, None, None]          # 128 x 512 distinct perturbations
+    states = (csv['states'][None, None] + scale * ds[None]).reshape(B, N + 1, 4)
+    inputs = (csv['inputs'][None, None] + scale * du[None]).reshape(B, N, 1)
+    states[40000], inputs[40000] = states[3], inputs[3]                    # duplicate
+    ws = amd.Workspace('acrobot', N, B, float(g['dt']))
+    ws.set_weights(g['Qk'], g['Rk'], g['QT'])
+    ws.upload(_lib.F_PARAMS, g['params'])
+    ws.upload(_lib.F_STATES, states)
+    ws.upload(_lib.F_INPUTS, inputs)
+    ws.ltvlqr()
+    ws.sync()
+    K = ws.download(_lib.F_KFB)
+    assert K.shape == (B, N, 1, 4) and np.isfinite(K).all()
+    assert np.all(ws.download(_lib.F_STATUS) == 0)
+    assert rel_err(K[0], g['K']) < TOL                                     # the reference's own output
+    assert np.array_equal(K[3], K[40000])
+    sample = [1, 511, 513, 30000, 65535]
+    Ko = oracle.ltvlqr_batched('acrobot', states[sample], inputs[sample], g['Qk'], g['Rk'], g['QT'], float(g['dt']), g['params'])
+    for i, b in enumerate(sample):
+        assert rel_err(K[b], Ko[i]) < TOL, b
+
+
+def test_c4_cartpole_131072(amd, oracle):
+    """configs[3], one GPU's shard: cartpole swing-up, 131 072 problems, N=1000, 8 concurrent line-search alphas"""
+    g = golden('cartpole_solve')
+    B, N = 131072, 1000
+    rng = np.random.default_rng(2)
+    init = rng.uniform(-0.1, 0.1, (B, 4))
+    guess = 0.05 * np.random.default_rng(22).standard_normal((512, N, 1))
+    guess = np.ascontiguousarray(np.broadcast_to(guess[None], (B // 512, 512, N, 1)).reshape(B, N, 1))
+    init[100000], guess[100000] = init[5], guess[5]
+    ws = solve_ws(amd, 'cartpole', g, init, guess, g['target'], 10, W=8)
+    assert ws.info()['pipeline'] == 'fused' and ws.info()['n_alpha_parallel'] == 8
+    sample = np.array([0, 5, 64, 65535, 100000, 131071])
+    trace, status, iters, cost = check_properties(amd, ws, 'cartpole', g, init, sample)
+    assert cost[5] == cost[100000] and np.array_equal(trace[5], trace[100000], equal_nan=True)
+    # cartpole amplifies rounding ~10x per iteration: compare the first iterations only
+    compare_sample_with_oracle(oracle, 'cartpole', g, init, guess, g['target'], ws, [0, 64, 131071], 3)
+
+
+def test_c5_quadcopter_32768(amd, oracle):
+    """configs[4], one GPU's shard: quadcopter (n=12, m=4), 32 768 problems with per-problem targets, N=400"""
+    g = golden('quadcopter_solve')
+    B, N = 32768, 400
+    rng = np.random.default_rng(3)
+    init = np.zeros((B, 12))
+    target = np.tile(g['target'], (B, 1))
+    target[:, :3] += rng.uniform(-0.5, 0.5, (B, 3))
+    guess = np.ascontiguousarray(np.broadcast_to(g['guess'][None], (B, N, 4)))
+    target[20000] = target[9]
+    ws = solve_ws(amd, 'quadcopter', g, init, guess, target, 10, target_batched=True)
+    sample = np.array([0, 9, 20000, 32767])
+    trace, status, iters, cost = check_properties(amd, ws, 'quadcopter', g, init, sample)
+    assert cost[9] == cost[20000]
+    compare_sample_with_oracle(oracle, 'quadcopter', g, init, guess, target, ws, [0, 9, 32767], 10)
