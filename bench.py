@@ -78,6 +78,7 @@ def main():
     ap.add_argument('--alphas', type=int, default=0, help='concurrent line-search trials per problem (0 = auto)')
     ap.add_argument('--cpu-sample', type=int, default=256)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--streams', type=int, default=0, help='independent sub-batches of solve(), one HIP stream each (0 = library default)')
     ap.add_argument('--force-dist', action='store_true', help='take the torch.distributed (RCCL) path even with one rank')
     args = ap.parse_args()
 
@@ -105,7 +106,7 @@ def main():
     cfg = acrobot_c2(args.batch, seed=rank)
     B, N = args.batch, cfg['N']
     ws = ilqr_amd.Workspace(cfg['system'], N, B, cfg['dt'], want_trace=True, n_iterations=args.iterations,
-                            n_alpha_parallel=args.alphas, device=local_rank)
+                            n_alpha_parallel=args.alphas, device=local_rank, n_streams=args.streams)
     ws.set_weights(cfg['Qk'], cfg['Rk'], cfg['QT'])
     ws.upload(_lib.F_INIT, cfg['init'])
     ws.upload(_lib.F_TARGET, cfg['target'])

@@ -84,7 +84,8 @@ struct KArgs {
     int zero_first;
     int n_trials;          // line-search trials with alpha > low_learning_rate
     int state_rows;        // rows per problem in X (N+1)
-    long long n_tiles;
+    long long n_tiles;     // tiles this launch covers (a sub-batch of the workspace)
+    long long tile0;       // first tile of the sub-batch
     double dt, low_red, armijo_thr, quu_reg;
     double* X;             // [tile][state_rows][n][64]
     double* U;             // [tile][N][m][64]
@@ -388,7 +389,7 @@ template <class S>
 __global__ void __launch_bounds__(64) k_rollout(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
-    const long long tile = blockIdx.x;
+    const long long tile = a.tile0 + blockIdx.x;
     const int lane = threadIdx.x;
     const long long b = tile * TILE + lane;
     double x[n], p[np], target[n], Rk[m * m], QT[n * n];
@@ -426,7 +427,7 @@ template <class S>
 __global__ void __launch_bounds__(64) k_cost(const KArgs a)
 {
     constexpr int n = S::n, m = S::m;
-    const long long tile = blockIdx.x;
+    const long long tile = a.tile0 + blockIdx.x;
     const int lane = threadIdx.x;
     double x[n], target[n], Rk[m * m], QT[n * n];
     load_col<n>(a.TARGET + (size_t)tile * n * TILE + lane, target);
@@ -489,7 +490,7 @@ template <class S>
 __global__ void __launch_bounds__(64) k_backward(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
-    const long long tile = blockIdx.x;
+    const long long tile = a.tile0 + blockIdx.x;
     const int lane = threadIdx.x;
     const long long b = tile * TILE + lane;
     const bool act = a.active[b] != 0;
@@ -610,15 +611,21 @@ __device__ __forceinline__ double closed_loop(const KArgs& a, const double* Xp, 
 // ballot over the lane group -- not the lowest cost.  Rounds of W trials repeat until accepted or exhausted.
 // ------------------------------------------------------------------------------------------------
 template <class S, int W, bool CKPT>
-__global__ void __launch_bounds__(256) k_linesearch(const KArgs a)
+#ifndef LS_WAVES_PER_EU
+#define LS_WAVES_PER_EU 2
+#endif
+__global__ void __launch_bounds__(W == 64 ? 512 : 256, LS_WAVES_PER_EU) k_linesearch(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
     constexpr int G = TILE / W;
-    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // logical block: neighbours (2k, 2k+1) sit 8 physical block ids apart (same XCD under round-robin dispatch)
+    const unsigned pb = blockIdx.x, nb16 = gridDim.x & ~15u;
+    const unsigned lb = pb < nb16 ? (pb & ~15u) + ((pb & 7u) << 1) + ((pb >> 3) & 1u) : pb;
+    const long long wave = ((long long)lb * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     const int grp = lane / W, al = lane % W;
-    const long long b = wave * G + grp;
-    if (wave * G >= a.Bpad) return;
+    if (wave * G >= a.n_tiles * TILE) return;
+    const long long b = a.tile0 * TILE + wave * G + grp;
     const long long tile = b >> 6;
     const int pl = (int)(b & 63);
     const bool act = a.active[b] != 0;
@@ -679,7 +686,7 @@ template <class S, bool ACCEPT>
 __global__ void __launch_bounds__(64) k_forward(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
-    const long long tile = blockIdx.x;
+    const long long tile = a.tile0 + blockIdx.x;
     const int lane = threadIdx.x;
     const long long b = tile * TILE + lane;
     bool run = true;
@@ -744,7 +751,7 @@ template <class S>
 __global__ void __launch_bounds__(64) k_accept_par(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
-    const long long tile = blockIdx.x / a.n_seg;
+    const long long tile = a.tile0 + blockIdx.x / a.n_seg;
     const int seg = (int)(blockIdx.x % a.n_seg);
     const int lane = threadIdx.x;
     const long long b = tile * TILE + lane;
@@ -808,7 +815,7 @@ __global__ void __launch_bounds__(64) k_linearize(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
     const int chunks = (a.N + LIN_TS - 1) / LIN_TS;
-    const long long tile = blockIdx.x / chunks;
+    const long long tile = a.tile0 + blockIdx.x / chunks;
     const int chunk = (int)(blockIdx.x % chunks);
     const int lane = threadIdx.x;
     const long long b = tile * TILE + lane;
@@ -874,7 +881,7 @@ template <class S>
 __global__ void __launch_bounds__(64) k_riccati(const KArgs a)
 {
     constexpr int n = S::n, m = S::m;
-    const long long tile = blockIdx.x;
+    const long long tile = a.tile0 + blockIdx.x;
     const int lane = threadIdx.x;
     const long long b = tile * TILE + lane;
     const bool act = a.active[b] != 0;
@@ -926,7 +933,7 @@ template <class S>
 __global__ void __launch_bounds__(64) k_ltvlqr(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
-    const long long tile = blockIdx.x;
+    const long long tile = a.tile0 + blockIdx.x;
     const int lane = threadIdx.x;
     double p[np], Qk[n * n], Rk[m * m], P[n * n];
     load_col<np>(a.PARAMS + (size_t)tile * np * TILE + lane, p);
@@ -1140,6 +1147,10 @@ struct ilqr_ws {
     int n, m, np, N, W, n_trials, want_trace;
     long long B, Bpad, tiles;
     hipStream_t stream;
+    int n_sub;                       // sub-batches of solve(), each a contiguous tile range on its own stream
+    hipStream_t sub_stream[4];
+    hipEvent_t sub_start, sub_done[4];
+    long long sub_tile0[5];
     double *X2, *U2, *CKPT, *LIN;
     int split, ck, n_seg, n_lin;
     double *X, *U, *G, *KFB, *KFF, *XO, *UO, *INIT, *TARGET, *PARAMS, *WTS, *alphas, *alpha_pp, *cost, *new_cost, *dJ, *trace;
@@ -1162,7 +1173,7 @@ KArgs make_args(ilqr_ws* ws, int it)
     KArgs a;
     memset(&a, 0, sizeof(a));
     a.N = ws->N; a.it = it; a.n_iter = ws->d.n_iterations; a.zero_first = ws->d.zero_first_state;
-    a.n_trials = ws->n_trials; a.state_rows = ws->state_rows; a.n_tiles = ws->tiles;
+    a.n_trials = ws->n_trials; a.state_rows = ws->state_rows; a.n_tiles = ws->tiles; a.tile0 = 0;
     a.dt = ws->d.dt; a.low_red = ws->d.low_expected_reduction; a.armijo_thr = ws->d.armijo_threshold;
     a.quu_reg = ws->d.quu_reg;
     a.X2 = ws->X2; a.U2 = ws->U2; a.CKPT = ws->CKPT; a.LIN = ws->LIN; a.ck = ws->ck; a.n_seg = ws->n_seg;
@@ -1187,18 +1198,18 @@ int with_system(int sys, F&& fn)
 }
 
 struct ProfScope {
-    ilqr_ws* ws; int kid; hipEvent_t a, b; bool on;
-    ProfScope(ilqr_ws* w, int k) : ws(w), kid(k), a(nullptr), b(nullptr), on(w->profiling)
+    ilqr_ws* ws; int kid; hipStream_t st; hipEvent_t a, b; bool on;
+    ProfScope(ilqr_ws* w, int k, hipStream_t s) : ws(w), kid(k), st(s), a(nullptr), b(nullptr), on(w->profiling)
     {
         if (on) {
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
-            (void)hipEventRecord(a, ws->stream);
+            (void)hipEventRecord(a, st);
         }
     }
     ~ProfScope()
     {
         if (on) {
-            (void)hipEventRecord(b, ws->stream);
+            (void)hipEventRecord(b, st);
             ws->events.push_back({a, b, kid});
         }
     }
@@ -1211,14 +1222,18 @@ int check_launch(const char* what)
     return 0;
 }
 
+// Line-search launch geometry.  A workgroup covers 8 consecutive problems, i.e. one full 64-byte segment of every
+// 512-byte tile row, so the rows it streams are fetched once per CU (W = 64: 8 waves, else 4 waves x 64/W problems;
+// W < 32 covers more).  Workgroups are dealt round-robin over the 8 XCDs, so logical neighbours (which share 128-byte
+// L2 lines) are mapped to block ids 8 apart = the same XCD's L2.  Placement is a speed matter only.
 template <class S, int W>
-void launch_ls(ilqr_ws* ws, const KArgs& a, bool ckpt)
+void launch_ls(hipStream_t st, const KArgs& a, bool ckpt)
 {
-    const long long waves = ws->Bpad * W / TILE;
-    const int wpb = 4;   // 256 threads
+    const long long waves = a.n_tiles * W;          // tiles * 64 problems * W lanes / 64
+    constexpr int wpb = W == 64 ? 8 : 4;
     const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
-    if (ckpt) hipLaunchKernelGGL((k_linesearch<S, W, true>), dim3(grid), dim3(256), 0, ws->stream, a);
-    else hipLaunchKernelGGL((k_linesearch<S, W, false>), dim3(grid), dim3(256), 0, ws->stream, a);
+    if (ckpt) hipLaunchKernelGGL((k_linesearch<S, W, true>), dim3(grid), dim3(64 * wpb), 0, st, a);
+    else hipLaunchKernelGGL((k_linesearch<S, W, false>), dim3(grid), dim3(64 * wpb), 0, st, a);
 }
 
 int set_device(const ilqr_ws* ws)
@@ -1357,40 +1372,104 @@ int fill_i32(ilqr_ws* ws, int* p, int v)
     return check_launch("k_fill_i32");
 }
 
+// launch one pass over the whole batch (sub < 0, workspace stream) or over sub-batch `sub` (its own stream)
 template <class F>
-int run_pass(ilqr_ws* ws, int kid, int it, const char* name, F&& launch)
+int run_pass(ilqr_ws* ws, int kid, int it, const char* name, F&& launch, int sub = -1)
 {
     if (!ws) return fail(-1, "null workspace");
     int rc = set_device(ws);
     if (rc) return rc;
-    const KArgs a = make_args(ws, it);
-    ProfScope ps(ws, kid);
+    KArgs a = make_args(ws, it);
+    hipStream_t st = ws->stream;
+    if (sub >= 0) {
+        a.tile0 = ws->sub_tile0[sub];
+        a.n_tiles = ws->sub_tile0[sub + 1] - ws->sub_tile0[sub];
+        st = ws->sub_stream[sub];
+    }
+    if (a.n_tiles <= 0) return 0;
+    ProfScope ps(ws, kid, st);
     return with_system(ws->d.system_id, [&](auto S) {
-        launch(S, a);
+        launch(S, a, st);
         return check_launch(name);
     });
 }
 
-int ws_linearize(ilqr_ws* ws, bool copy)
+int ws_linearize(ilqr_ws* ws, bool copy, int sub = -1)
 {
     const int chunks = (ws->N + LIN_TS - 1) / LIN_TS;
-    const unsigned grid = (unsigned)(ws->tiles * chunks);
-    return run_pass(ws, KID_LINEARIZE, 0, "k_linearize", [&](auto S, const KArgs& a) {
-        if (copy) hipLaunchKernelGGL((k_linearize<decltype(S), true>), dim3(grid), dim3(64), 0, ws->stream, a);
-        else hipLaunchKernelGGL((k_linearize<decltype(S), false>), dim3(grid), dim3(64), 0, ws->stream, a);
-    });
+    return run_pass(ws, KID_LINEARIZE, 0, "k_linearize", [&](auto S, const KArgs& a, hipStream_t st) {
+        const unsigned grid = (unsigned)(a.n_tiles * chunks);
+        if (copy) hipLaunchKernelGGL((k_linearize<decltype(S), true>), dim3(grid), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_linearize<decltype(S), false>), dim3(grid), dim3(64), 0, st, a);
+    }, sub);
 }
-int ws_riccati(ilqr_ws* ws, int it)
+int ws_riccati(ilqr_ws* ws, int it, int sub = -1)
 {
-    return run_pass(ws, KID_BACKWARD, it, "k_riccati", [&](auto S, const KArgs& a) {
-        hipLaunchKernelGGL(k_riccati<decltype(S)>, dim3((unsigned)ws->tiles), dim3(64), 0, ws->stream, a);
-    });
+    return run_pass(ws, KID_BACKWARD, it, "k_riccati", [&](auto S, const KArgs& a, hipStream_t st) {
+        hipLaunchKernelGGL(k_riccati<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+    }, sub);
 }
-int ws_accept_par(ilqr_ws* ws, int it)
+int ws_accept_par(ilqr_ws* ws, int it, int sub = -1)
 {
-    return run_pass(ws, KID_ACCEPT, it, "k_accept_par", [&](auto S, const KArgs& a) {
-        hipLaunchKernelGGL(k_accept_par<decltype(S)>, dim3((unsigned)(ws->tiles * ws->n_seg)), dim3(64), 0, ws->stream, a);
-    });
+    return run_pass(ws, KID_ACCEPT, it, "k_accept_par", [&](auto S, const KArgs& a, hipStream_t st) {
+        hipLaunchKernelGGL(k_accept_par<decltype(S)>, dim3((unsigned)(a.n_tiles * ws->n_seg)), dim3(64), 0, st, a);
+    }, sub);
+}
+int ws_rollout(ilqr_ws* ws, int sub = -1)
+{
+    return run_pass(ws, KID_ROLLOUT, 0, "k_rollout", [&](auto S, const KArgs& a, hipStream_t st) {
+        hipLaunchKernelGGL(k_rollout<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+    }, sub);
+}
+int ws_backward(ilqr_ws* ws, int it, int sub = -1)
+{
+    return run_pass(ws, KID_BACKWARD, it, "k_backward", [&](auto S, const KArgs& a, hipStream_t st) {
+        hipLaunchKernelGGL(k_backward<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+    }, sub);
+}
+int ws_linesearch(ilqr_ws* ws, int sub = -1)
+{
+    return run_pass(ws, KID_LINESEARCH, 0, "k_linesearch", [&](auto S, const KArgs& a, hipStream_t st) {
+        using T = decltype(S);
+        const bool ck = ws->split != 0;
+        switch (ws->W) {
+            case 1: launch_ls<T, 1>(st, a, ck); break;
+            case 2: launch_ls<T, 2>(st, a, ck); break;
+            case 4: launch_ls<T, 4>(st, a, ck); break;
+            case 8: launch_ls<T, 8>(st, a, ck); break;
+            case 16: launch_ls<T, 16>(st, a, ck); break;
+            case 32: launch_ls<T, 32>(st, a, ck); break;
+            default: launch_ls<T, 64>(st, a, ck); break;
+        }
+    }, sub);
+}
+int ws_accept(ilqr_ws* ws, int it, int sub = -1)
+{
+    return run_pass(ws, KID_ACCEPT, it, "k_forward<accept>", [&](auto S, const KArgs& a, hipStream_t st) {
+        hipLaunchKernelGGL((k_forward<decltype(S), true>), dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+    }, sub);
+}
+// solve() of one sub-batch (or of the whole batch when sub < 0): ilqr.py:162-207
+int ws_solve_chain(ilqr_ws* ws, int sub)
+{
+    int rc;
+    if ((rc = ws_rollout(ws, sub))) return rc;                       // :162-164
+    if (ws->split) {
+        if ((rc = ws_linearize(ws, false, sub))) return rc;          // A_t, B_t of the initial trajectory (:96-97)
+        for (int it = 0; it < ws->d.n_iterations; ++it) {            // :170
+            if ((rc = ws_riccati(ws, it, sub))) return rc;           // :99-135, :173-179
+            if ((rc = ws_linesearch(ws, sub))) return rc;            // :180-202 (+ checkpoints)
+            if ((rc = ws_accept_par(ws, it, sub))) return rc;        // :194-207, segments in parallel
+            if ((rc = ws_linearize(ws, true, sub))) return rc;       // accepted trajectory back + A_t, B_t for the next pass
+        }
+        return 0;
+    }
+    for (int it = 0; it < ws->d.n_iterations; ++it) {                // :170
+        if ((rc = ws_backward(ws, it, sub))) return rc;              // :173-179
+        if ((rc = ws_linesearch(ws, sub))) return rc;                // :180-202
+        if ((rc = ws_accept(ws, it, sub))) return rc;                // :194-207
+    }
+    return 0;
 }
 
 int validate_desc(const ilqr_desc* d)
@@ -1402,6 +1481,7 @@ int validate_desc(const ilqr_desc* d)
     if (d->n_iterations < 0) return fail(-1, "n_iterations must be >= 0");
     const int w = d->n_alpha_parallel;
     if (w != 0 && (w < 1 || w > 64 || (w & (w - 1)) != 0)) return fail(-1, "n_alpha_parallel must be 0 or a power of two <= 64");
+    if (d->n_streams < 0 || d->n_streams > 4) return fail(-1, "n_streams must be 0 (default: 1) to 4");
     if (d->pipeline < 0 || d->pipeline > 2) return fail(-1, "pipeline must be 0 (auto), 1 (fused) or 2 (split)");
     if (!(d->learning_speed > 0.0 && d->learning_speed < 1.0)) return fail(-1, "learning_speed must be in (0,1)");
     if (!(d->low_learning_rate > 0.0 && d->low_learning_rate < 1.0)) return fail(-1, "low_learning_rate must be in (0,1)");
@@ -1427,6 +1507,7 @@ void ilqr_desc_default(ilqr_desc* d)
     d->armijo_threshold = 0.1;
     d->quu_reg = 0.0;
     d->pipeline = 0;
+    d->n_streams = 0;
 }
 
 int ilqr_abi_version(void) { return ILQR_ABI_VERSION; }
@@ -1528,9 +1609,9 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
     }
     ws->n_trials = n_trials;
     int W = d->n_alpha_parallel;
-    if (W == 0) {   // auto: enough waves to fill 256 CUs x 4 SIMDs a few times over, at least 8 lanes per problem
+    if (W == 0) {   // auto: about two waves per SIMD (256 CUs x 4 SIMDs), 8 to 32 trials per problem and round
         W = 8;
-        while (W < 64 && ws->Bpad * (long long)(W * 2) / TILE <= 4096) W *= 2;
+        while (W < 32 && ws->Bpad * (long long)(W * 2) / TILE <= 4096) W *= 2;
     }
     ws->W = W;
     // pipeline: with few tiles the horizon-sequential kernels occupy one wave per tile and leave most of the 1024 SIMDs
@@ -1568,6 +1649,16 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
     }
     hipError_t e = hipStreamCreate(&ws->stream);
     if (e != hipSuccess) { ilqr_ws_destroy(ws); return fail(-100 - (int)e, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    ws->n_sub = d->n_streams > 0 ? d->n_streams : 1;
+    if (ws->n_sub > ws->tiles) ws->n_sub = (int)ws->tiles;
+    for (int sb = 0; sb <= ws->n_sub; ++sb) ws->sub_tile0[sb] = ws->tiles * sb / ws->n_sub;
+    if (ws->n_sub > 1) {
+        HIPCHK(hipEventCreateWithFlags(&ws->sub_start, hipEventDisableTiming));
+        for (int sb = 0; sb < ws->n_sub; ++sb) {
+            HIPCHK(hipStreamCreate(&ws->sub_stream[sb]));
+            HIPCHK(hipEventCreateWithFlags(&ws->sub_done[sb], hipEventDisableTiming));
+        }
+    }
     HIPCHK(hipMemcpy(ws->alphas, alphas, sizeof(alphas), hipMemcpyHostToDevice));
     HIPCHK(hipMemsetAsync(ws->WTS, 0, (2 * n * n + m * m) * 8, ws->stream));
     HIPCHK(hipMemsetAsync(ws->dJ, 0, 3 * Bp * 8, ws->stream));
@@ -1596,6 +1687,13 @@ int ilqr_ws_destroy(ilqr_ws* ws)
                     ws->alpha_pp, ws->cost, ws->new_cost, ws->dJ, ws->trace, ws->active, ws->iters, ws->status, ws->acc_j,
                     ws->ls_rounds, ws->accepts, ws->staging};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (ws->n_sub > 1) {
+        if (ws->sub_start) (void)hipEventDestroy(ws->sub_start);
+        for (int sb = 0; sb < ws->n_sub; ++sb) {
+            if (ws->sub_stream[sb]) { (void)hipStreamSynchronize(ws->sub_stream[sb]); (void)hipStreamDestroy(ws->sub_stream[sb]); }
+            if (ws->sub_done[sb]) (void)hipEventDestroy(ws->sub_done[sb]);
+        }
+    }
     if (ws->stream) (void)hipStreamDestroy(ws->stream);
     delete ws;
     return 0;
@@ -1657,44 +1755,20 @@ int ilqr_ws_reset(ilqr_ws* ws)
     return 0;
 }
 
-int ilqr_ws_rollout(ilqr_ws* ws)
-{
-    return run_pass(ws, KID_ROLLOUT, 0, "k_rollout", [&](auto S, const KArgs& a) {
-        hipLaunchKernelGGL(k_rollout<decltype(S)>, dim3((unsigned)ws->tiles), dim3(64), 0, ws->stream, a);
-    });
-}
+int ilqr_ws_rollout(ilqr_ws* ws) { return ws_rollout(ws); }
 int ilqr_ws_cost(ilqr_ws* ws)
 {
-    return run_pass(ws, KID_COST, 0, "k_cost", [&](auto S, const KArgs& a) {
-        hipLaunchKernelGGL(k_cost<decltype(S)>, dim3((unsigned)ws->tiles), dim3(64), 0, ws->stream, a);
+    return run_pass(ws, KID_COST, 0, "k_cost", [&](auto S, const KArgs& a, hipStream_t st) {
+        hipLaunchKernelGGL(k_cost<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
     });
 }
-int ilqr_ws_backward(ilqr_ws* ws, int32_t iteration)
-{
-    return run_pass(ws, KID_BACKWARD, iteration, "k_backward", [&](auto S, const KArgs& a) {
-        hipLaunchKernelGGL(k_backward<decltype(S)>, dim3((unsigned)ws->tiles), dim3(64), 0, ws->stream, a);
-    });
-}
-int ilqr_ws_linesearch(ilqr_ws* ws)
-{
-    return run_pass(ws, KID_LINESEARCH, 0, "k_linesearch", [&](auto S, const KArgs& a) {
-        using T = decltype(S);
-        switch (ws->W) {
-            case 1: launch_ls<T, 1>(ws, a, ws->split != 0); break;
-            case 2: launch_ls<T, 2>(ws, a, ws->split != 0); break;
-            case 4: launch_ls<T, 4>(ws, a, ws->split != 0); break;
-            case 8: launch_ls<T, 8>(ws, a, ws->split != 0); break;
-            case 16: launch_ls<T, 16>(ws, a, ws->split != 0); break;
-            case 32: launch_ls<T, 32>(ws, a, ws->split != 0); break;
-            default: launch_ls<T, 64>(ws, a, ws->split != 0); break;
-        }
-    });
-}
+int ilqr_ws_backward(ilqr_ws* ws, int32_t iteration) { return ws_backward(ws, iteration); }
+int ilqr_ws_linesearch(ilqr_ws* ws) { return ws_linesearch(ws); }
 int ilqr_ws_accept(ilqr_ws* ws, int32_t iteration)
 {
-    return run_pass(ws, KID_ACCEPT, iteration, "k_forward<accept>", [&](auto S, const KArgs& a) {
-        hipLaunchKernelGGL((k_forward<decltype(S), true>), dim3((unsigned)ws->tiles), dim3(64), 0, ws->stream, a);
-    });
+    if (ws && ws->split) return fail(-1, "ilqr_ws_accept is the fused schedule's accept step; this workspace uses the split "
+                                         "schedule (create it with pipeline = 1 to drive the passes one by one)");
+    return ws_accept(ws, iteration);
 }
 int ilqr_ws_forward(ilqr_ws* ws, int32_t with_cost)
 {
@@ -1703,16 +1777,16 @@ int ilqr_ws_forward(ilqr_ws* ws, int32_t with_cost)
     int rc = set_device(ws);
     if (rc) return rc;
     if ((rc = ensure_forward_out(ws))) return rc;
-    return run_pass(ws, KID_FORWARD, 0, "k_forward", [&](auto S, const KArgs& a0) {
+    return run_pass(ws, KID_FORWARD, 0, "k_forward", [&](auto S, const KArgs& a0, hipStream_t st) {
         KArgs a = a0;
         a.XO = ws->XO; a.UO = ws->UO;
-        hipLaunchKernelGGL((k_forward<decltype(S), false>), dim3((unsigned)ws->tiles), dim3(64), 0, ws->stream, a);
+        hipLaunchKernelGGL((k_forward<decltype(S), false>), dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
     });
 }
 int ilqr_ws_ltvlqr(ilqr_ws* ws)
 {
-    return run_pass(ws, KID_LTVLQR, 0, "k_ltvlqr", [&](auto S, const KArgs& a) {
-        hipLaunchKernelGGL(k_ltvlqr<decltype(S)>, dim3((unsigned)ws->tiles), dim3(64), 0, ws->stream, a);
+    return run_pass(ws, KID_LTVLQR, 0, "k_ltvlqr", [&](auto S, const KArgs& a, hipStream_t st) {
+        hipLaunchKernelGGL(k_ltvlqr<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
     });
 }
 
@@ -1720,21 +1794,16 @@ int ilqr_ws_solve(ilqr_ws* ws)
 {
     int rc;
     if ((rc = ilqr_ws_reset(ws))) return rc;
-    if ((rc = ilqr_ws_rollout(ws))) return rc;                 // ilqr.py:162-164
-    if (ws->split) {
-        if ((rc = ws_linearize(ws, false))) return rc;         // A_t, B_t of the initial trajectory (:96-97)
-        for (int it = 0; it < ws->d.n_iterations; ++it) {      // :170
-            if ((rc = ws_riccati(ws, it))) return rc;          // :99-135, :173-179
-            if ((rc = ilqr_ws_linesearch(ws))) return rc;      // :180-202 (+ checkpoints)
-            if ((rc = ws_accept_par(ws, it))) return rc;       // :194-207, segments in parallel
-            if ((rc = ws_linearize(ws, true))) return rc;      // copy the accepted trajectory back, A_t, B_t for the next pass
-        }
-        return 0;
-    }
-    for (int it = 0; it < ws->d.n_iterations; ++it) {          // :170
-        if ((rc = ilqr_ws_backward(ws, it))) return rc;        // :173-179
-        if ((rc = ilqr_ws_linesearch(ws))) return rc;          // :180-202
-        if ((rc = ilqr_ws_accept(ws, it))) return rc;          // :194-207
+    if (ws->n_sub <= 1) return ws_solve_chain(ws, -1);
+    // sub-batches are independent tile ranges: each runs its own launch chain on its own stream, so one sub-batch's
+    // horizon-sequential kernels (few waves) overlap another's line search (many waves)
+    HIPCHK(hipEventRecord(ws->sub_start, ws->stream));
+    for (int sb = 0; sb < ws->n_sub; ++sb) HIPCHK(hipStreamWaitEvent(ws->sub_stream[sb], ws->sub_start, 0));
+    for (int sb = 0; sb < ws->n_sub; ++sb)
+        if ((rc = ws_solve_chain(ws, sb))) return rc;
+    for (int sb = 0; sb < ws->n_sub; ++sb) {
+        HIPCHK(hipEventRecord(ws->sub_done[sb], ws->sub_stream[sb]));
+        HIPCHK(hipStreamWaitEvent(ws->stream, ws->sub_done[sb], 0));
     }
     return 0;
 }

@@ -16,7 +16,7 @@ from .symbolic_dynamics import system_of
 
 class ilqr:
     def __init__(self, init_state, target_state, initial_guess, dt, start_time, end_time, f_disc, A, B, Q_k, R_k, Q_T,
-                 parameters, n_iterations, device=0, n_alpha_parallel=0, verbose=None, zero_first_state=True, pipeline=0):
+                 parameters, n_iterations, device=0, n_alpha_parallel=0, verbose=None, zero_first_state=True, pipeline=0, n_streams=0):
         self.init_state_ = init_state
         self.target_state_ = target_state
         self.inputs_ = initial_guess
@@ -48,6 +48,7 @@ class ilqr:
         self.n_alpha_parallel_ = n_alpha_parallel
         self.zero_first_state_ = zero_first_state
         self.pipeline_ = pipeline              # 0 auto, 1 fused, 2 split kernel schedule (same results)
+        self.n_streams_ = n_streams            # independent sub-batches of solve(), one HIP stream each
         self.verbose_ = (not self.batched_) if verbose is None else verbose
 
         n, m, npar = _lib.system_dims(self.system_)
@@ -87,7 +88,7 @@ class ilqr:
         _, pb = self._params()
         return _lib.make_desc(self.system_, self.n_timesteps_, self.batch_, self.dt_, n_iterations=n_iterations,
                               n_alpha_parallel=self.n_alpha_parallel_, zero_first_state=self.zero_first_state_,
-                              device=self.device_, target_batched=tb, params_batched=pb, pipeline=self.pipeline_)
+                              device=self.device_, target_batched=tb, params_batched=pb, pipeline=self.pipeline_, n_streams=self.n_streams_)
 
     # ------------------------------------------------------------------ ilqr.py:30-47
     def rollout(self):

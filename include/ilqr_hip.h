@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ILQR_ABI_VERSION 2
+#define ILQR_ABI_VERSION 3
 
 /* systems compiled into the library (sympy-generated __device__ dynamics, ilqr_amd/csrc/dynamics/) */
 enum { ILQR_SYS_PENDULUM = 0, ILQR_SYS_ACROBOT = 1, ILQR_SYS_CARTPOLE = 2, ILQR_SYS_QUADCOPTER = 3 };
@@ -58,6 +58,10 @@ typedef struct ilqr_desc {
     int32_t pipeline;             /* kernel schedule of solve(): 0 auto, 1 fused (backward | line search | accept),
                                      2 split (Jacobians and the accept re-roll in parallel over time; small batches).
                                      Results are bit-identical for both. */
+    int32_t n_streams;            /* solve() splits the batch into this many independent sub-batches (contiguous problem
+                                     ranges), each with its own launch chain on its own HIP stream, so that one sub-batch's
+                                     horizon-sequential kernels overlap another's line search.  0/1: one chain; max 4.
+                                     Results do not depend on it. */
 } ilqr_desc;
 
 void ilqr_desc_default(ilqr_desc* d);

@@ -248,6 +248,27 @@ def test_fused_and_split_pipelines_agree_bitwise(amd, system):
 
 
 @pytest.mark.parametrize('pipeline', [1, 2])
+def test_sub_batches_on_streams_do_not_change_results(amd, pipeline):
+    """solve() split into 3 independent sub-batches (uneven tile ranges: 200 problems = 4 tiles) on 3 HIP streams"""
+    from ilqr_amd import _lib
+    g, init, guess = random_batch('pendulum', 200, 120, seed=9)
+    outs = []
+    for n_streams in (1, 3):
+        ws = amd.Workspace('pendulum', 120, 200, float(g['dt']), want_trace=True, n_iterations=4, pipeline=pipeline,
+                           n_streams=n_streams)
+        ws.set_weights(g['Qk'], g['Rk'], g['QT'])
+        for f, a in ((_lib.F_PARAMS, g['params']), (_lib.F_INIT, init), (_lib.F_TARGET, g['target']), (_lib.F_GUESS, guess)):
+            ws.upload(f, a)
+        ws.solve()
+        ws.solve()                                    # repeatable: the guess is kept
+        ws.sync()
+        outs.append([ws.download(f) for f in (_lib.F_STATES, _lib.F_INPUTS, _lib.F_KFB, _lib.F_KFF, _lib.F_COST, _lib.F_TRACE,
+                                              _lib.F_STATUS, _lib.F_ITERS)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize('pipeline', [1, 2])
 def test_acrobot_example_both_pipelines(amd, pipeline):
     """N = 3000 is not a multiple of the 64-step checkpoint interval: last segment is short"""
     g = golden('acrobot_solve')
