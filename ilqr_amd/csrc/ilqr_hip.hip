@@ -546,18 +546,27 @@ __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double
                                                     const int t1)
 {
     constexpr int n = S::n, m = S::m;
+    // Rows of the reference trajectory and gains for step t+1 are loaded while step t computes -- in registers when the
+    // per-step record is small (n <= 4: 10 doubles), else (quadcopter: 68 doubles) the loads are left to the scheduler.
+    // Either way row t+1 of X is read before the STORE below overwrites it (in-place accept).
+    constexpr bool PREFETCH = (n + 2 * m + m * n) <= 16;
     double cost = 0.0;
     double xb[n], ub[m], K[m * n], kf[m];
     load_col<n>(Xp + (size_t)t0 * n * TILE, xb); load_col<m>(Up + (size_t)t0 * m * TILE, ub);
-    load_col<m * n>(Kp + (size_t)t0 * (m * n) * TILE, K); load_col<m>(kp + (size_t)t0 * m * TILE, kf);
+    if constexpr (PREFETCH) { load_col<m * n>(Kp + (size_t)t0 * (m * n) * TILE, K); load_col<m>(kp + (size_t)t0 * m * TILE, kf); }
     int next_ck = CKPT ? a.ck : 0;
     for (int t = t0; t < t1; ++t) {
-        double xb2[n], ub2[m], K2[m * n], kf2[m];                                      // prefetch step t+1 (also makes
-        const int tn = t + 1 < t1 ? t + 1 : t;                                         // the in-place accept safe: the old
-        load_col<n>(Xp + (size_t)tn * n * TILE, xb2);                                  // row t+1 is read before it is
-        load_col<m>(Up + (size_t)tn * m * TILE, ub2);                                  // overwritten below)
-        load_col<m * n>(Kp + (size_t)tn * (m * n) * TILE, K2);
-        load_col<m>(kp + (size_t)tn * m * TILE, kf2);
+        double xb2[n], ub2[m], K2[m * n], kf2[m];
+        const int tn = t + 1 < t1 ? t + 1 : t;
+        load_col<n>(Xp + (size_t)tn * n * TILE, xb2);
+        load_col<m>(Up + (size_t)tn * m * TILE, ub2);
+        if constexpr (PREFETCH) {
+            load_col<m * n>(Kp + (size_t)tn * (m * n) * TILE, K2);
+            load_col<m>(kp + (size_t)tn * m * TILE, kf2);
+        } else {
+            load_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K);
+            load_col<m>(kp + (size_t)t * m * TILE, kf);
+        }
         if constexpr (CKPT) {
             if (t == next_ck) {                                                        // state entering segment t / ck
                 double* c = ckp + (size_t)(t / a.ck) * n * TILE;
@@ -586,9 +595,13 @@ __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double
 #pragma unroll
         for (int i = 0; i < n; ++i) xb[i] = xb2[i];
 #pragma unroll
-        for (int j = 0; j < m; ++j) { ub[j] = ub2[j]; kf[j] = kf2[j]; }
+        for (int j = 0; j < m; ++j) ub[j] = ub2[j];
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (int i = 0; i < m * n; ++i) K[i] = K2[i];
+            for (int j = 0; j < m; ++j) kf[j] = kf2[j];
+#pragma unroll
+            for (int i = 0; i < m * n; ++i) K[i] = K2[i];
+        }
     }
     return cost;
 }
@@ -614,7 +627,7 @@ template <class S, int W, bool CKPT>
 #ifndef LS_WAVES_PER_EU
 #define LS_WAVES_PER_EU 2
 #endif
-__global__ void __launch_bounds__(W == 64 ? 512 : 256, LS_WAVES_PER_EU) k_linesearch(const KArgs a)
+__global__ void __launch_bounds__(W == 64 ? 512 : 256, (S::n <= 4 ? LS_WAVES_PER_EU : 1)) k_linesearch(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
     constexpr int G = TILE / W;
@@ -926,6 +939,260 @@ __global__ void __launch_bounds__(64) k_riccati(const KArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_riccati_grp: the same recursion as k_riccati with a GROUP of GL lanes per problem (64/GL problems per wave),
+// for systems whose V_xx does not fit one lane's registers (n = 12: V_xx, Q_xx and A^T V_xx are 3 x 144 doubles).
+//   * between steps lane j of a group holds COLUMN j of V_xx and V_x[j];
+//   * column phase: (A^T V_xx)[:, j] and (B^T V_xx)[:, j] from the lane's own column -- the sums run over the
+//     structural non-zeros of A / B, identical code for every lane; the Jacobian entries are read from LDS where the
+//     group staged the step's LIN row (dense, expanded through a per-lane index map);
+//   * transpose through LDS (padded rows, conflict free); row phase: lane i forms row i of Q_xx = (A^T V_xx) A,
+//     column i of Q_ux and K, Q_x[i]; Q_uu, Q_u, the inverse and k are small and computed by every lane;
+//   * Q_ux and K are shared through LDS for the four-term V_xx update of row i (ilqr.py:125), then rows -> columns.
+// One wave per workgroup: the LDS hand-offs are ordered by program order (the barriers only pin the compiler).
+// Operation order follows the reference ((A^T V) A, (B^T V) A, ...), as Riccati<S>::step does.
+// ------------------------------------------------------------------------------------------------
+template <class S>
+struct Grp {
+    static constexpr int n = S::n, m = S::m;
+    static constexpr int GL = n <= 2 ? 2 : (n <= 4 ? 4 : (n <= 8 ? 8 : 16));
+    static constexpr int P = TILE / GL;                 // problems per wave
+    static constexpr int KA = (n * n + GL - 1) / GL;    // dense A entries staged per lane
+    static constexpr int KB = (n * m + GL - 1) / GL;
+    static constexpr int LD = n + 1;                    // padded leading dimension of the transpose buffer
+    static constexpr int oA = 0, oB = oA + n * n, oT = oB + n * m, oBtV = oT + n * LD, oQux = oBtV + m * n,
+                         oK = oQux + m * n, oVx = oK + m * n, oU = oVx + n, SLOT = ((oU + m + 1) | 1);
+};
+
+// index of dense entry e of A (or B) in the step's LIN row; -1 structural zero, -2 structural one
+template <class S, bool IS_B>
+__device__ __forceinline__ int lin_index(const int e)
+{
+    constexpr int cnt_all = IS_B ? S::n * S::m : S::n * S::n;
+    int cnt = IS_B ? Lin<S>::nA : 0;
+    int res = -1;
+#pragma unroll
+    for (int q = 0; q < cnt_all; ++q) {
+        const char kd = IS_B ? S::b_kind(q) : S::a_kind(q);
+        if (q == e) res = kd == 'x' ? cnt : (kd == '1' ? -2 : -1);
+        if (kd == 'x') ++cnt;
+    }
+    return res;
+}
+
+template <class S>
+__global__ void __launch_bounds__(64) k_riccati_grp(const KArgs a)
+{
+    using G = Grp<S>;
+    constexpr int n = S::n, m = S::m, GL = G::GL, P = G::P, NL = Lin<S>::n_lin, LD = G::LD, KA = G::KA, KB = G::KB;
+    __shared__ double sh[P * G::SLOT];
+    const int lane = threadIdx.x;
+    const int grp = lane / GL, c = lane % GL;
+    const long long b = a.tile0 * TILE + (long long)blockIdx.x * P + grp;
+    const long long tile = b >> 6;
+    const int pl = (int)(b & 63);
+    const bool act = a.active[b] != 0;
+    if (__ballot(act) == 0ull) return;
+    double* s = sh + grp * G::SLOT;
+    const bool row = c < n;
+    const int cc = row ? c : n - 1;                     // surplus lanes shadow the last row / column and never store
+    // per-lane staging map
+    int aidx[KA], bidx[KB];
+#pragma unroll
+    for (int q = 0; q < KA; ++q) aidx[q] = (c + GL * q) < n * n ? lin_index<S, false>(c + GL * q) : -1;
+#pragma unroll
+    for (int q = 0; q < KB; ++q) bidx[q] = (c + GL * q) < n * m ? lin_index<S, true>(c + GL * q) : -1;
+    double Qkr[n], Rk[m * m], Vc[n], vx;
+#pragma unroll
+    for (int j = 0; j < n; ++j) Qkr[j] = a.WTS[cc * n + j];                            // row i of Q_k
+    load_uniform<m * m>(a.WTS + n * n, Rk);
+    const double* QT = a.WTS + n * n + m * m;
+#pragma unroll
+    for (int r = 0; r < n; ++r) Vc[r] = QT[r * n + cc];                                // :67 column j of Q_T
+    const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + pl;
+    const double* Up = a.U + (size_t)tile * a.N * m * TILE + pl;
+    const double* Lp = a.LIN + (size_t)tile * a.N * NL * TILE + pl;
+    double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + pl;
+    double* kp = a.KFF + (size_t)tile * a.N * m * TILE + pl;
+    {
+        double target[n], xN[n];
+        load_col<n>(a.TARGET + (size_t)tile * n * TILE + pl, target);
+        load_col<n>(Xp + (size_t)a.N * n * TILE, xN);
+        double acc = 0.0;                                                              // :68-70 V_x[j] = (Q_T ed)[j]
+#pragma unroll
+        for (int q = 0; q < n; ++q) acc = __builtin_fma(QT[cc * n + q], xN[q] - target[q], acc);
+        vx = acc;
+    }
+    double stA[KA], stB[KB], stU;
+    auto load_stage = [&](const int t) {
+        const double* l = Lp + (size_t)t * NL * TILE;
+#pragma unroll
+        for (int q = 0; q < KA; ++q) stA[q] = aidx[q] >= 0 ? l[(size_t)aidx[q] * TILE] : (aidx[q] == -2 ? 1.0 : 0.0);
+#pragma unroll
+        for (int q = 0; q < KB; ++q) stB[q] = bidx[q] >= 0 ? l[(size_t)bidx[q] * TILE] : (bidx[q] == -2 ? 1.0 : 0.0);
+        stU = c < m ? Up[((size_t)t * m + c) * TILE] : 0.0;
+    };
+    load_stage(a.N - 1);
+    double ecr = 0.0, ecr_g = 0.0, ecr_h = 0.0;
+    bool ok = true;
+    for (int t = a.N - 1; t >= 0; --t) {                                               // :82
+        // ---- stage A_t, B_t, u_t and V_x into LDS
+#pragma unroll
+        for (int q = 0; q < KA; ++q) if (c + GL * q < n * n) s[G::oA + c + GL * q] = stA[q];
+#pragma unroll
+        for (int q = 0; q < KB; ++q) if (c + GL * q < n * m) s[G::oB + c + GL * q] = stB[q];
+        if (c < m) s[G::oU + c] = stU;
+        if (row) s[G::oVx + c] = vx;
+        __syncthreads();
+        load_stage(t > 0 ? t - 1 : 0);                                                 // prefetch the next step's row
+        // ---- column phase (lane j): A^T V_xx and B^T V_xx, column j
+        double AtV[n], BtV[m];
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double acc = 0.0; bool first = true;
+#pragma unroll
+            for (int r = 0; r < n; ++r) acc_term(acc, first, S::a_kind(r * n + i), s[G::oA + r * n + i], Vc[r]);
+            AtV[i] = acc;
+        }
+#pragma unroll
+        for (int l = 0; l < m; ++l) {
+            double acc = 0.0; bool first = true;
+#pragma unroll
+            for (int r = 0; r < n; ++r) acc_term(acc, first, S::b_kind(r * m + l), s[G::oB + r * m + l], Vc[r]);
+            BtV[l] = acc;
+        }
+        if (row) {
+#pragma unroll
+            for (int i = 0; i < n; ++i) s[G::oT + i * LD + c] = AtV[i];
+#pragma unroll
+            for (int l = 0; l < m; ++l) s[G::oBtV + l * n + c] = BtV[l];
+        }
+        __syncthreads();
+        // ---- row phase (lane i)
+        double Ri[n], Qxx[n], Qux[m], Quu[m * m], Quu_inv[m * m], Qu[m], u[m], k[m], Kc[m];
+#pragma unroll
+        for (int r = 0; r < n; ++r) Ri[r] = s[G::oT + cc * LD + r];                    // (A^T V_xx)[i][:]
+#pragma unroll
+        for (int j = 0; j < n; ++j) {                                                  // :103 row i of Q_xx
+            double acc = 0.0; bool first = true;
+#pragma unroll
+            for (int r = 0; r < n; ++r) acc_term(acc, first, S::a_kind(r * n + j), s[G::oA + r * n + j], Ri[r]);
+            Qxx[j] = Qkr[j] + acc;
+        }
+#pragma unroll
+        for (int l = 0; l < m; ++l) {                                                  // :101 column i of Q_ux (dense in r)
+            double acc = 0.0;
+#pragma unroll
+            for (int r = 0; r < n; ++r) acc = __builtin_fma(s[G::oBtV + l * n + r], s[G::oA + r * n + cc], acc);
+            Qux[l] = acc;
+        }
+#pragma unroll
+        for (int l = 0; l < m; ++l) {                                                  // :102 Q_uu (every lane)
+#pragma unroll
+            for (int l2 = 0; l2 < m; ++l2) {
+                double acc = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(acc, first, S::b_kind(r * m + l2), s[G::oB + r * m + l2], s[G::oBtV + l * n + r]);
+                Quu[l * m + l2] = Rk[l * m + l2] + acc;
+            }
+            Quu[l * m + l] += a.quu_reg;
+        }
+        double Qx = 0.0;                                                               // :99 Q_x[i] (dense in r)
+#pragma unroll
+        for (int r = 0; r < n; ++r) Qx = __builtin_fma(s[G::oA + r * n + cc], s[G::oVx + r], Qx);
+#pragma unroll
+        for (int l = 0; l < m; ++l) u[l] = s[G::oU + l];
+#pragma unroll
+        for (int l = 0; l < m; ++l) {                                                  // :93,:100 Q_u (every lane)
+            double lu = 0.0;
+#pragma unroll
+            for (int l2 = 0; l2 < m; ++l2) lu = __builtin_fma(Rk[l * m + l2], u[l2], lu);
+            double acc = 0.0; bool first = true;
+#pragma unroll
+            for (int r = 0; r < n; ++r) acc_term(acc, first, S::b_kind(r * m + l), s[G::oB + r * m + l], s[G::oVx + r]);
+            Qu[l] = lu + acc;
+        }
+        ok = Riccati<S>::inv_spd(Quu, Quu_inv) && ok;                                  // :106
+#pragma unroll
+        for (int l = 0; l < m; ++l) {                                                  // :107-108
+            double acc = 0.0, acc2 = 0.0;
+#pragma unroll
+            for (int l2 = 0; l2 < m; ++l2) {
+                acc = __builtin_fma(-Quu_inv[l * m + l2], Qu[l2], acc);
+                acc2 = __builtin_fma(-Quu_inv[l * m + l2], Qux[l2], acc2);
+            }
+            k[l] = acc;
+            Kc[l] = acc2;
+        }
+        if (act) {
+            if (row) {
+#pragma unroll
+                for (int l = 0; l < m; ++l) Kp[((size_t)t * (m * n) + l * n + c) * TILE] = Kc[l];   // :112
+            }
+#pragma unroll
+            for (int l = 0; l < m; ++l) if (c == l) kp[((size_t)t * m + l) * TILE] = k[l];          // :111
+        }
+        double g = 0.0, h = 0.0;                                                       // :115-116
+#pragma unroll
+        for (int l = 0; l < m; ++l) g = __builtin_fma(-Qu[l], k[l], g);
+#pragma unroll
+        for (int l = 0; l < m; ++l) {
+            double acc = 0.0;
+#pragma unroll
+            for (int l2 = 0; l2 < m; ++l2) acc = __builtin_fma(0.5 * k[l2], Quu[l2 * m + l], acc);
+            h = __builtin_fma(acc, k[l], h);
+        }
+        const double cur = g + h;
+        ecr_g += g; ecr_h += h; ecr += cur;                                            // :119-121
+        if (row) {
+#pragma unroll
+            for (int l = 0; l < m; ++l) { s[G::oQux + l * n + c] = Qux[l]; s[G::oK + l * n + c] = Kc[l]; }
+        }
+        __syncthreads();
+        // ---- value function update, row i (:124-125)
+        double KtQuu[m];
+#pragma unroll
+        for (int l = 0; l < m; ++l) {
+            double acc = 0.0;
+#pragma unroll
+            for (int l2 = 0; l2 < m; ++l2) acc = __builtin_fma(Kc[l2], Quu[l2 * m + l], acc);
+            KtQuu[l] = acc;
+        }
+        {
+            double v1 = 0.0, v2 = 0.0, v3 = 0.0;
+#pragma unroll
+            for (int l = 0; l < m; ++l) v1 = __builtin_fma(KtQuu[l], k[l], v1);
+#pragma unroll
+            for (int l = 0; l < m; ++l) v2 = __builtin_fma(Kc[l], Qu[l], v2);
+#pragma unroll
+            for (int l = 0; l < m; ++l) v3 = __builtin_fma(Qux[l], k[l], v3);
+            vx = ((Qx + v1) + v2) + v3;
+        }
+        double Vr[n];
+#pragma unroll
+        for (int j = 0; j < n; ++j) {
+            double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+            for (int l = 0; l < m; ++l) t1 = __builtin_fma(Qux[l], s[G::oK + l * n + j], t1);
+#pragma unroll
+            for (int l = 0; l < m; ++l) t2 = __builtin_fma(Kc[l], s[G::oQux + l * n + j], t2);
+#pragma unroll
+            for (int l = 0; l < m; ++l) t3 = __builtin_fma(KtQuu[l], s[G::oK + l * n + j], t3);
+            Vr[j] = ((Qxx[j] + t1) + t2) + t3;
+        }
+        // rows -> columns
+        if (row) {
+#pragma unroll
+            for (int j = 0; j < n; ++j) s[G::oT + c * LD + j] = Vr[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < n; ++r) Vc[r] = s[G::oT + r * LD + cc];
+        __syncthreads();
+    }
+    if (act && c == 0) backward_epilogue(a, tile, pl, b, ecr, ecr_g, ecr_h, ok);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_ltvlqr: ltvlqr.py:3-28.  One lane per problem; P stays in VGPRs.
 // K = -inv(R + B'PB) B'PA,  P <- Q + A'PA - (A'PB) inv(R + B'PB) (B'PA)
 // ------------------------------------------------------------------------------------------------
@@ -1152,7 +1419,7 @@ struct ilqr_ws {
     hipEvent_t sub_start, sub_done[4];
     long long sub_tile0[5];
     double *X2, *U2, *CKPT, *LIN;
-    int split, ck, n_seg, n_lin;
+    int split, grp, ck, n_seg, n_lin;
     double *X, *U, *G, *KFB, *KFF, *XO, *UO, *INIT, *TARGET, *PARAMS, *WTS, *alphas, *alpha_pp, *cost, *new_cost, *dJ, *trace;
     int *active, *iters, *status, *acc_j, *ls_rounds, *accepts;
     void* staging;
@@ -1406,7 +1673,9 @@ int ws_linearize(ilqr_ws* ws, bool copy, int sub = -1)
 int ws_riccati(ilqr_ws* ws, int it, int sub = -1)
 {
     return run_pass(ws, KID_BACKWARD, it, "k_riccati", [&](auto S, const KArgs& a, hipStream_t st) {
-        hipLaunchKernelGGL(k_riccati<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+        using T = decltype(S);
+        if (ws->grp) hipLaunchKernelGGL(k_riccati_grp<T>, dim3((unsigned)(a.n_tiles * Grp<T>::GL)), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(k_riccati<T>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
     }, sub);
 }
 int ws_accept_par(ilqr_ws* ws, int it, int sub = -1)
@@ -1482,6 +1751,7 @@ int validate_desc(const ilqr_desc* d)
     const int w = d->n_alpha_parallel;
     if (w != 0 && (w < 1 || w > 64 || (w & (w - 1)) != 0)) return fail(-1, "n_alpha_parallel must be 0 or a power of two <= 64");
     if (d->n_streams < 0 || d->n_streams > 4) return fail(-1, "n_streams must be 0 (default: 1) to 4");
+    if (d->riccati < 0 || d->riccati > 2) return fail(-1, "riccati must be 0 (auto), 1 (lane per problem) or 2 (lane group)");
     if (d->pipeline < 0 || d->pipeline > 2) return fail(-1, "pipeline must be 0 (auto), 1 (fused) or 2 (split)");
     if (!(d->learning_speed > 0.0 && d->learning_speed < 1.0)) return fail(-1, "learning_speed must be in (0,1)");
     if (!(d->low_learning_rate > 0.0 && d->low_learning_rate < 1.0)) return fail(-1, "low_learning_rate must be in (0,1)");
@@ -1508,6 +1778,7 @@ void ilqr_desc_default(ilqr_desc* d)
     d->quu_reg = 0.0;
     d->pipeline = 0;
     d->n_streams = 0;
+    d->riccati = 0;
 }
 
 int ilqr_abi_version(void) { return ILQR_ABI_VERSION; }
@@ -1619,6 +1890,10 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
     // keep the fused kernels (no LIN / checkpoint traffic).
     ws->split = d->pipeline == 2 || (d->pipeline == 0 && ws->tiles < 1024);
     if (d->n_iterations == 0) ws->split = 0;
+    // Riccati recursion: one lane per problem while V_xx fits its registers (n <= 4), a lane group with LDS hand-offs
+    // beyond (always through the split schedule, which provides LIN); riccati = 1 / 2 forces lane / group
+    ws->grp = d->riccati == 2 || (d->riccati == 0 && ws->n > 4);
+    if (ws->grp) ws->split = 1;
     ws->ck = CKPT_INTERVAL;
     ws->n_seg = (ws->N + ws->ck - 1) / ws->ck;
     ws->n_lin = with_system(d->system_id, [&](auto S) { return Lin<decltype(S)>::n_lin; });
@@ -1762,7 +2037,14 @@ int ilqr_ws_cost(ilqr_ws* ws)
         hipLaunchKernelGGL(k_cost<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
     });
 }
-int ilqr_ws_backward(ilqr_ws* ws, int32_t iteration) { return ws_backward(ws, iteration); }
+int ilqr_ws_backward(ilqr_ws* ws, int32_t iteration)
+{
+    if (ws && ws->split) {
+        int rc = ws_linearize(ws, false);
+        return rc ? rc : ws_riccati(ws, iteration);
+    }
+    return ws_backward(ws, iteration);
+}
 int ilqr_ws_linesearch(ilqr_ws* ws) { return ws_linesearch(ws); }
 int ilqr_ws_accept(ilqr_ws* ws, int32_t iteration)
 {

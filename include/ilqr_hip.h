@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ILQR_ABI_VERSION 3
+#define ILQR_ABI_VERSION 4
 
 /* systems compiled into the library (sympy-generated __device__ dynamics, ilqr_amd/csrc/dynamics/) */
 enum { ILQR_SYS_PENDULUM = 0, ILQR_SYS_ACROBOT = 1, ILQR_SYS_CARTPOLE = 2, ILQR_SYS_QUADCOPTER = 3 };
@@ -62,6 +62,8 @@ typedef struct ilqr_desc {
                                      ranges), each with its own launch chain on its own HIP stream, so that one sub-batch's
                                      horizon-sequential kernels overlap another's line search.  0/1: one chain; max 4.
                                      Results do not depend on it. */
+    int32_t riccati;              /* mapping of the backward recursion: 0 auto (one lane per problem for n <= 4, a group of
+                                     lanes with LDS hand-offs for larger n), 1 lane, 2 group.  Group implies pipeline 2. */
 } ilqr_desc;
 
 void ilqr_desc_default(ilqr_desc* d);

@@ -247,6 +247,26 @@ def test_fused_and_split_pipelines_agree_bitwise(amd, system):
         assert np.array_equal(a, b, equal_nan=True)
 
 
+@pytest.mark.parametrize('system', ['pendulum', 'acrobot', 'cartpole'])
+def test_group_riccati_matches_lane_riccati(amd, system):
+    """the lane-group backward recursion (LDS hand-offs; the quadcopter's default) against the one-lane-per-problem
+    recursion on the systems where both exist: same operation order, so the same numbers to rounding"""
+    from ilqr_amd import _lib
+    g, init, guess = random_batch(system, 70, 130, seed=4)
+    outs = []
+    for riccati in (1, 2):
+        ws = amd.Workspace(system, 130, 70, float(g['dt']), want_trace=True, n_iterations=4, pipeline=2, riccati=riccati)
+        ws.set_weights(g['Qk'], g['Rk'], g['QT'])
+        for f, a in ((_lib.F_PARAMS, g['params']), (_lib.F_INIT, init), (_lib.F_TARGET, g['target']), (_lib.F_GUESS, guess)):
+            ws.upload(f, a)
+        ws.solve()
+        ws.sync()
+        outs.append([ws.download(f) for f in (_lib.F_STATES, _lib.F_INPUTS, _lib.F_KFB, _lib.F_KFF, _lib.F_COST, _lib.F_DJ)])
+        assert np.all(ws.download(_lib.F_STATUS) != 3)
+    for a, b in zip(*outs):
+        assert rel_err(a, b) < 1e-11
+
+
 @pytest.mark.parametrize('pipeline', [1, 2])
 def test_sub_batches_on_streams_do_not_change_results(amd, pipeline):
     """solve() split into 3 independent sub-batches (uneven tile ranges: 200 problems = 4 tiles) on 3 HIP streams"""
