@@ -76,9 +76,10 @@ def main():
     ap.add_argument('--batch', type=int, default=4096, help='problems per GPU')
     ap.add_argument('--iterations', type=int, default=10)
     ap.add_argument('--alphas', type=int, default=0, help='concurrent line-search trials per problem (0 = auto)')
-    ap.add_argument('--cpu-sample', type=int, default=256)
+    ap.add_argument('--cpu-sample', type=int, default=4096, help='problems of the batch the CPU baseline solves')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--streams', type=int, default=0, help='independent sub-batches of solve(), one HIP stream each (0 = library default)')
+    ap.add_argument('--riccati', type=int, default=0, help='backward recursion mapping: 0 auto, 1 lane per problem, 2 lane group')
     ap.add_argument('--force-dist', action='store_true', help='take the torch.distributed (RCCL) path even with one rank')
     args = ap.parse_args()
 
@@ -89,6 +90,11 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
         args.gpus = world
+
+    # stdout carries exactly ONE JSON line: everything libraries print there (RCCL's version banner, ...) goes to stderr
+    json_out = os.fdopen(os.dup(1), 'w')
+    sys.stdout.flush()
+    os.dup2(2, 1)
 
     import ilqr_amd
     from ilqr_amd import _lib
@@ -106,7 +112,7 @@ def main():
     cfg = acrobot_c2(args.batch, seed=rank)
     B, N = args.batch, cfg['N']
     ws = ilqr_amd.Workspace(cfg['system'], N, B, cfg['dt'], want_trace=True, n_iterations=args.iterations,
-                            n_alpha_parallel=args.alphas, device=local_rank, n_streams=args.streams)
+                            n_alpha_parallel=args.alphas, device=local_rank, n_streams=args.streams, riccati=args.riccati)
     ws.set_weights(cfg['Qk'], cfg['Rk'], cfg['QT'])
     ws.upload(_lib.F_INIT, cfg['init'])
     ws.upload(_lib.F_TARGET, cfg['target'])
@@ -190,6 +196,18 @@ def main():
     else:
         roofline = dict(bound='hbm', achieved=round(dk['gbs'], 2), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(hbm_frac, 5),
                         traffic=None)
+    # HBM traffic of that kernel from the committed rocprofv3 PMC passes (collected separately: counters cannot be read
+    # from inside this process), only when they were taken on this very configuration
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+        c = pmc['config']
+        if (c['system'], c['batch'], c['n_timesteps'], c['n_alpha_parallel'], c['pipeline']) == \
+                (cfg['system'], B, N, W, info['pipeline']) and args.iterations == 10:
+            roofline['traffic'] = round(pmc['kernels']['k_' + dominant]['hbm_bytes_per_launch'] / 1e9, 3)
+            roofline['traffic_unit'] = 'GB per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)'
+            roofline['algorithmic_bytes_per_launch_GB'] = round(dk['bytes_per_launch'] / 1e9, 3)
+    except (OSError, KeyError, ValueError):
+        pass
     roofline.update(kernel='k_' + dominant, ms_per_launch=round(dk['ms_per_launch'], 4), launches=dk['launches'],
                     hbm_gbs=round(dk['gbs'], 2), hbm_frac=round(hbm_frac, 5), fp64_tflops=round(dk['tflops'], 4),
                     fp64_frac=round(fp_frac, 5), n_alpha_parallel=W,
@@ -226,8 +244,11 @@ def main():
         out['cpu_baseline'] = {'value': round(v, 3), 'unit': 'solves/s', 'cores': threads, 'kind': 'port',
                                'sample': 'first %d of the %d problems, same %d iterations, oracle/ilqr_oracle.c with OpenMP, %.1f s'
                                          % (sample, B, args.iterations, secs),
-                               'gpu_vs_cpu_cost_max_rel_diff': float(np.max(np.abs(cost[:sample] - r['cost']) / np.abs(r['cost'])))}
-    print(json.dumps(out))
+                               'gpu_vs_cpu_cost_max_rel_diff': float(np.max(np.abs(cost[:sample] - r['cost']) / np.abs(r['cost']))),
+                               'gpu_vs_cpu_cost_frac_within_1e-8': float(np.mean(np.abs(cost[:sample] - r['cost']) <= 1e-8 * np.abs(r['cost']))),
+                               'gpu_vs_cpu_same_exit_status_frac': float(np.mean(status[:sample] == r['status']))}
+    json_out.write(json.dumps(out) + '\n')
+    json_out.flush()
     if dist is not None:
         dist.destroy_process_group()
 
