@@ -37,6 +37,7 @@ sparsity tables), ``ILQR_DYN_SINCOS`` and ``ILQR_DYN_TAN`` -- hipcc for gfx950 i
 The generated headers are committed: the GPU box never runs sympy.
 """
 import ast
+import re
 import inspect
 import os
 import sys
@@ -175,11 +176,27 @@ def _function(model, what, mat):
     lines = ['ILQR_DYN_FN void ilqr_dyn_%s_%s(const double* x, const double* u, const double dt, '
              'const double* p, double* out)' % (model.name, what), '{']
     lines.append('    (void)x; (void)u; (void)dt; (void)p;')
+    # f only: sin/cos of (a + b) where a and b already have their pair -> angle addition (ILQR_DYN_SINCOS_SUM).  In f
+    # every trig value is scaled by dt before it meets the state, so the ~2e-16 absolute error of the sum formula is far
+    # below an ulp of x; the Jacobians (A, B entries are dt * expression, no large addend) keep the direct evaluation.
+    sums = {}
+    if what == 'f':
+        for arg, i in em.trig_args:
+            for a, ia in em.trig_args:
+                for b, ib in em.trig_args:
+                    if arg == '(%s + %s)' % (a, b) and i not in (ia, ib):
+                        sums[i] = (a, ia, b, ib)
     for d in em.trig_defs:
-        lines.append('    ' + d)
+        idx = re.match(r'double sn(\d+),', d)
+        if idx is None or int(idx.group(1)) not in sums:
+            lines.append('    ' + d)
+    for i, (a, ia, b, ib) in sorted(sums.items()):
+        lines.append('    double sn%d, cs%d; ILQR_DYN_SINCOS_SUM(%s, %s, sn%d, cs%d, sn%d, cs%d, sn%d, cs%d); (void)sn%d; (void)cs%d;'
+                     % (i, i, a, b, ia, ia, ib, ib, i, i, i, i))
     if em.trig_args:
-        # one rarely-taken branch for all arguments of this function (keeps the fast paths in one basic block)
-        lines.append('    if (%s) {' % ' || '.join('ILQR_DYN_TRIG_BIG(%s)' % a for a, _ in em.trig_args))
+        # one rarely-taken branch for all arguments of this function (keeps the fast paths in one basic block); a sum
+        # of two small angles is small enough for the sum formula, so only the plain arguments are tested
+        lines.append('    if (%s) {' % ' || '.join('ILQR_DYN_TRIG_BIG(%s)' % a for a, i in em.trig_args if i not in sums))
         for a, i in em.trig_args:
             lines.append('        ILQR_DYN_SINCOS_SLOW(%s, sn%d, cs%d);' % (a, i, i))
         lines.append('    }')
@@ -205,7 +222,7 @@ def generate(name):
                  ' * Reference: /root/reference/python/symbolic_dynamics.py:23-25,88-90 (lambdify call sites).\n'
                  ' * Row-major: f out[n], A out[n*n] (A[i][j] = out[i*n+j]), B out[n*m].\n'
                  ' * The includer defines ILQR_DYN_FN, ILQR_DYN_CONST, ILQR_DYN_SINCOS(x, s, c), ILQR_DYN_SINCOS_SLOW(x, s, c),\n'
-                 ' * ILQR_DYN_TRIG_BIG(x), ILQR_DYN_TAN(x), ILQR_DYN_RCP(d), ILQR_DYN_DIV(a, d, rd) and must compile\n'
+                 ' * ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c), ILQR_DYN_TRIG_BIG(x), ILQR_DYN_TAN(x), ILQR_DYN_RCP(d), ILQR_DYN_DIV(a, d, rd) and must compile\n'
                  ' * with -ffp-contract=off. */'
                  % (name, name))
     parts.append('#ifndef ILQR_DYN_%s_H\n#define ILQR_DYN_%s_H' % (up, up))

@@ -14,11 +14,16 @@
 #ifndef ILQR_FAST_TRIG_H
 #define ILQR_FAST_TRIG_H
 
-// out of line on purpose: keeps ocml's general reduction (and its registers) out of the time-step loops
-__device__ __attribute__((noinline)) void ilqr_sincos_slow(const double x, double* s_out, double* c_out)
+// out of line on purpose: keeps ocml's general reduction (and its registers) out of the time-step loops.  The pair
+// comes back BY VALUE (registers): out-pointers would pin sn/cs of every caller to scratch memory, and the scratch
+// round trip's s_waitcnt vmcnt(0) also drains the trajectory prefetch of the time-step loop.
+struct ilqr_sc { double sinv, cosv; };
+__device__ __attribute__((noinline)) ilqr_sc ilqr_sincos_slow(const double x)
 {
-    *s_out = sin(x);
-    *c_out = cos(x);
+    ilqr_sc r;
+    r.sinv = sin(x);
+    r.cosv = cos(x);
+    return r;
 }
 
 // fast path only; the caller patches arguments with !(|x| < 1e6) through ilqr_sincos_slow (one branch per function)
@@ -54,7 +59,35 @@ __device__ __forceinline__ void ilqr_sincos_fast(const double x, double& s_out, 
     c_out = ((q + 1) & 2) ? -c : c;
 }
 
-// a / d with a shared, correctly rounded reciprocal rd = 1/d: one multiply and one fused residual correction
+// sin and cos of t = fl(a + b) -- the argument the reference hands to numpy -- from the pairs of a and b: angle addition
+// on the exact sum a + b = t + e (two-sum), then first order in the rounding error e (|e| < 2^-33 for |a|,|b| < 1e6, so
+// the neglected e^2/2 is < 1e-20).  12 instructions instead of a third range reduction + kernels (~50).  Absolute error
+// <= 3e-16 (the inputs' 0.78 ulp carried through), i.e. NOT relative near zeros of the result: the generator uses it only
+// in f, where every trig value is scaled by dt before it is added to the state.
+__device__ __forceinline__ void ilqr_sincos_sum(const double a, const double b, const double sa, const double ca,
+                                                const double sb, const double cb, double& s_out, double& c_out)
+{
+    const double t = a + b;
+    const double bb = t - a;
+    const double e = (a - (t - bb)) + (b - bb);
+    const double S = __builtin_fma(sa, cb, ca * sb);
+    const double C = __builtin_fma(ca, cb, -(sa * sb));
+    s_out = __builtin_fma(-C, e, S);
+    c_out = __builtin_fma(S, e, C);
+}
+
+// 1/d for the shared-reciprocal division below: hardware estimate + two Newton steps (what the compiler's own fp64
+// division does, minus its rescaling and special-case fix-up: 5 instructions instead of 11).  Within half an ulp of
+// 1/d in all but rare cases; d = 0 gives NaN (the IEEE quotient a/0 is inf or NaN: the trajectory is lost either way).
+__device__ __forceinline__ double ilqr_rcp(const double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    return r;
+}
+
+// a / d with a shared, (nearly always) correctly rounded reciprocal rd = 1/d: one multiply and one fused residual correction
 // (Markstein): equals the IEEE quotient except in rare half-ulp cases; exponent extremes are not rescaled (the
 // divisors of the generated dynamics are O(1) physical quantities).
 __device__ __forceinline__ double ilqr_div_shared(const double a, const double d, const double rd)

@@ -32,10 +32,11 @@
 #define ILQR_DYN_FN __device__ __forceinline__
 #define ILQR_DYN_CONST static constexpr
 #define ILQR_DYN_SINCOS(x, s, c) ilqr_sincos_fast((x), (s), (c))
-#define ILQR_DYN_SINCOS_SLOW(x, s, c) ilqr_sincos_slow((x), &(s), &(c))
+#define ILQR_DYN_SINCOS_SLOW(x, s, c) do { const ilqr_sc sc_ = ilqr_sincos_slow(x); (s) = sc_.sinv; (c) = sc_.cosv; } while (0)
+#define ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c) ilqr_sincos_sum((a), (b), (sa), (ca), (sb), (cb), (s), (c))
 #define ILQR_DYN_TRIG_BIG(x) (!(__builtin_fabs(x) < 1.0e6))
 #define ILQR_DYN_TAN(x) tan(x)
-#define ILQR_DYN_RCP(d) (1.0 / (d))
+#define ILQR_DYN_RCP(d) ilqr_rcp(d)
 #define ILQR_DYN_DIV(a, d, rd) ilqr_div_shared((a), (d), (rd))
 #include "dynamics/pendulum.h"
 #include "dynamics/acrobot.h"
