@@ -115,6 +115,9 @@ struct KArgs {
     int* status;
     int* acc_j;
     int* ls_rounds;
+    int ls_round;          // line search: round r evaluates trials [r*W, r*W + W)
+    int* ls_list;          // [2][Bpad] problems still searching after a round (ping-pong by round parity)
+    int* ls_count;         // [MAX_TRIALS] length of the list each round leaves (zeroed before round 0)
     int* accepts;
     double* trace;         // [tile][n_iter][6][64] or nullptr
     long long Bpad;
@@ -638,11 +641,21 @@ __global__ void __launch_bounds__(W == 64 ? 512 : 256, (S::n <= 4 ? LS_WAVES_PER
     const long long wave = ((long long)lb * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     const int grp = lane / W, al = lane % W;
-    if (wave * G >= a.n_tiles * TILE) return;
-    const long long b = a.tile0 * TILE + wave * G + grp;
+    const int r = a.ls_round;
+    long long b;
+    bool act;
+    if (r == 0) {                                            // every active problem of the (sub-)batch, in place
+        if (wave * G >= a.n_tiles * TILE) return;
+        b = a.tile0 * TILE + wave * G + grp;
+        act = a.active[b] != 0;
+    } else {                                                 // the problems round r-1 left searching, packed densely
+        const long long cnt = a.ls_count[r - 1], g = wave * G + grp;
+        if (wave * G >= cnt) return;
+        act = g < cnt;
+        b = act ? a.ls_list[(size_t)((r - 1) & 1) * a.Bpad + a.tile0 * TILE + g] : a.tile0 * TILE;
+    }
     const long long tile = b >> 6;
     const int pl = (int)(b & 63);
-    const bool act = a.active[b] != 0;
     if (__ballot(act) == 0ull) return;
     double x0[n], p[np], target[n], Rk[m * m], QT[n * n];
     load_col<n>(a.INIT + (size_t)tile * n * TILE + pl, x0);
@@ -656,37 +669,37 @@ __global__ void __launch_bounds__(W == 64 ? 512 : 256, (S::n <= 4 ? LS_WAVES_PER
     const double* Up = a.U + (size_t)tile * a.N * m * TILE + pl;
     const double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + pl;
     const double* kp = a.KFF + (size_t)tile * a.N * m * TILE + pl;
-    bool done = !act;
-    int accj = -1, rounds = 0;
-    double ncost = __builtin_nan("");
-    for (int r = 0; r * W < a.n_trials; ++r) {
-        const int j = r * W + al;
-        const bool valid = !done && j < a.n_trials;
-        if (__ballot(valid) == 0ull) break;
-        double c = __builtin_nan("");
-        bool okj = false;
-        if (valid) {
-            const double alpha = a.alphas[j];
-            double x[n];
+    const int j = r * W + al;
+    const bool valid = act && j < a.n_trials;
+    double c = __builtin_nan("");
+    bool okj = false;
+    if (valid) {
+        const double alpha = a.alphas[j];
+        double x[n];
 #pragma unroll
-            for (int i = 0; i < n; ++i) x[i] = x0[i];
-            double* ckp = CKPT ? a.CKPT + (size_t)b * a.n_seg * n * TILE + j : nullptr;
-            c = closed_loop<S, false, CKPT>(a, Xp, Up, Kp, kp, nullptr, nullptr, x, p, target, Rk, QT, alpha, ckp);
-            const double cost_difference = cur_cost - c;                               // :191
-            const double expected = alpha * dg + (alpha * alpha) * dh;                 // :192
-            okj = (cost_difference / expected) > a.armijo_thr;                         // :193 (NaN -> false)
-        }
-        if (!done) ++rounds;
-        const unsigned long long mask = __ballot(okj);
-        const unsigned long long gm = (W == 64) ? mask : ((mask >> (grp * W)) & ((1ull << (W % 64)) - 1ull));
-        const int first = gm != 0ull ? __ffsll((long long)gm) - 1 : 0;
-        const double cwin = __shfl(c, grp * W + first);
-        if (!done && gm != 0ull) { accj = r * W + first; ncost = cwin; done = true; }
+        for (int i = 0; i < n; ++i) x[i] = x0[i];
+        double* ckp = CKPT ? a.CKPT + (size_t)b * a.n_seg * n * TILE + j : nullptr;
+        c = closed_loop<S, false, CKPT>(a, Xp, Up, Kp, kp, nullptr, nullptr, x, p, target, Rk, QT, alpha, ckp);
+        const double cost_difference = cur_cost - c;                               // :191
+        const double expected = alpha * dg + (alpha * alpha) * dh;                 // :192
+        okj = (cost_difference / expected) > a.armijo_thr;                         // :193 (NaN -> false)
     }
+    const unsigned long long mask = __ballot(okj);
+    const unsigned long long gm = (W == 64) ? mask : ((mask >> (grp * W)) & ((1ull << (W % 64)) - 1ull));
+    const int first = gm != 0ull ? __ffsll((long long)gm) - 1 : 0;
+    const double cwin = __shfl(c, grp * W + first);
     if (al == 0 && act) {
-        a.acc_j[b] = accj;
-        a.new_cost[b] = ncost;
-        a.ls_rounds[b] += rounds;
+        a.ls_rounds[b] += 1;
+        if (gm != 0ull) {
+            a.acc_j[b] = r * W + first;
+            a.new_cost[b] = cwin;
+        } else if ((r + 1) * W < a.n_trials) {                                     // :200-202, next round's list
+            const int slot = atomicAdd(a.ls_count + r, 1);
+            a.ls_list[(size_t)(r & 1) * a.Bpad + a.tile0 * TILE + slot] = (int)b;
+        } else {                                                                   // :204 learning rate ran out
+            a.acc_j[b] = -1;
+            a.new_cost[b] = __builtin_nan("");
+        }
     }
 }
 
@@ -1422,7 +1435,7 @@ struct ilqr_ws {
     double *X2, *U2, *CKPT, *LIN;
     int split, grp, ck, n_seg, n_lin;
     double *X, *U, *G, *KFB, *KFF, *XO, *UO, *INIT, *TARGET, *PARAMS, *WTS, *alphas, *alpha_pp, *cost, *new_cost, *dJ, *trace;
-    int *active, *iters, *status, *acc_j, *ls_rounds, *accepts;
+    int *active, *iters, *status, *acc_j, *ls_rounds, *accepts, *ls_list, *ls_count;
     void* staging;
     size_t staging_bytes;
     size_t hbm_bytes;
@@ -1449,6 +1462,7 @@ KArgs make_args(ilqr_ws* ws, int it)
     a.INIT = ws->INIT; a.TARGET = ws->TARGET; a.PARAMS = ws->PARAMS; a.WTS = ws->WTS; a.alphas = ws->alphas;
     a.alpha_pp = ws->alpha_pp; a.cost = ws->cost; a.new_cost = ws->new_cost; a.dJ = ws->dJ; a.active = ws->active;
     a.iters = ws->iters; a.status = ws->status; a.acc_j = ws->acc_j; a.ls_rounds = ws->ls_rounds;
+    a.ls_round = 0; a.ls_list = ws->ls_list; a.ls_count = ws->ls_count;
     a.accepts = ws->accepts; a.trace = ws->want_trace ? ws->trace : nullptr; a.Bpad = ws->Bpad;
     return a;
 }
@@ -1467,7 +1481,7 @@ int with_system(int sys, F&& fn)
 
 struct ProfScope {
     ilqr_ws* ws; int kid; hipStream_t st; hipEvent_t a, b; bool on;
-    ProfScope(ilqr_ws* w, int k, hipStream_t s) : ws(w), kid(k), st(s), a(nullptr), b(nullptr), on(w->profiling)
+    ProfScope(ilqr_ws* w, int k, hipStream_t s) : ws(w), kid(k), st(s), a(nullptr), b(nullptr), on(w && w->profiling)
     {
         if (on) {
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
@@ -1642,7 +1656,7 @@ int fill_i32(ilqr_ws* ws, int* p, int v)
 
 // launch one pass over the whole batch (sub < 0, workspace stream) or over sub-batch `sub` (its own stream)
 template <class F>
-int run_pass(ilqr_ws* ws, int kid, int it, const char* name, F&& launch, int sub = -1)
+int run_pass(ilqr_ws* ws, int kid, int it, const char* name, F&& launch, int sub = -1, bool prof = true)
 {
     if (!ws) return fail(-1, "null workspace");
     int rc = set_device(ws);
@@ -1655,7 +1669,7 @@ int run_pass(ilqr_ws* ws, int kid, int it, const char* name, F&& launch, int sub
         st = ws->sub_stream[sub];
     }
     if (a.n_tiles <= 0) return 0;
-    ProfScope ps(ws, kid, st);
+    ProfScope ps(prof ? ws : nullptr, kid, st);
     return with_system(ws->d.system_id, [&](auto S) {
         launch(S, a, st);
         return check_launch(name);
@@ -1697,21 +1711,40 @@ int ws_backward(ilqr_ws* ws, int it, int sub = -1)
         hipLaunchKernelGGL(k_backward<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
     }, sub);
 }
+// One launch per round of W trials.  Round 0 runs every active problem in place; a problem none of whose W trials passed
+// appends itself to a list, and the next round runs exactly that list, packed into full waves (a round that is mostly
+// finished then occupies few SIMDs once each instead of trailing behind half-empty waves).  The host does not know the
+// list lengths: every round is launched at full size and the surplus workgroups return on their first load.
 int ws_linesearch(ilqr_ws* ws, int sub = -1)
 {
-    return run_pass(ws, KID_LINESEARCH, 0, "k_linesearch", [&](auto S, const KArgs& a, hipStream_t st) {
-        using T = decltype(S);
-        const bool ck = ws->split != 0;
-        switch (ws->W) {
-            case 1: launch_ls<T, 1>(st, a, ck); break;
-            case 2: launch_ls<T, 2>(st, a, ck); break;
-            case 4: launch_ls<T, 4>(st, a, ck); break;
-            case 8: launch_ls<T, 8>(st, a, ck); break;
-            case 16: launch_ls<T, 16>(st, a, ck); break;
-            case 32: launch_ls<T, 32>(st, a, ck); break;
-            default: launch_ls<T, 64>(st, a, ck); break;
-        }
-    }, sub);
+    if (!ws) return fail(-1, "null workspace");
+    int rc = set_device(ws);
+    if (rc) return rc;
+    hipStream_t st = sub >= 0 ? ws->sub_stream[sub] : ws->stream;
+    int* cnt = ws->ls_count + (size_t)(sub + 1) * MAX_TRIALS;
+    const int rounds = (ws->n_trials + ws->W - 1) / ws->W;
+    ProfScope ps(ws, KID_LINESEARCH, st);
+    if (rounds > 1) HIPCHK(hipMemsetAsync(cnt, 0, MAX_TRIALS * sizeof(int), st));
+    for (int r = 0; r < rounds; ++r) {
+        rc = run_pass(ws, KID_LINESEARCH, 0, "k_linesearch", [&](auto S, const KArgs& a0, hipStream_t s) {
+            using T = decltype(S);
+            KArgs a = a0;
+            a.ls_round = r;
+            a.ls_count = cnt;
+            const bool ck = ws->split != 0;
+            switch (ws->W) {
+                case 1: launch_ls<T, 1>(s, a, ck); break;
+                case 2: launch_ls<T, 2>(s, a, ck); break;
+                case 4: launch_ls<T, 4>(s, a, ck); break;
+                case 8: launch_ls<T, 8>(s, a, ck); break;
+                case 16: launch_ls<T, 16>(s, a, ck); break;
+                case 32: launch_ls<T, 32>(s, a, ck); break;
+                default: launch_ls<T, 64>(s, a, ck); break;
+            }
+        }, sub, false);
+        if (rc) return rc;
+    }
+    return 0;
 }
 int ws_accept(ilqr_ws* ws, int it, int sub = -1)
 {
@@ -1905,7 +1938,8 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
         {(void**)&ws->PARAMS, Bp * np * 8}, {(void**)&ws->WTS, (2 * n * n + m * m) * 8}, {(void**)&ws->alphas, MAX_TRIALS * 8},
         {(void**)&ws->alpha_pp, Bp * 8}, {(void**)&ws->cost, Bp * 8}, {(void**)&ws->new_cost, Bp * 8}, {(void**)&ws->dJ, 3 * Bp * 8},
         {(void**)&ws->active, Bp * 4}, {(void**)&ws->iters, Bp * 4}, {(void**)&ws->status, Bp * 4}, {(void**)&ws->acc_j, Bp * 4},
-        {(void**)&ws->ls_rounds, Bp * 4}, {(void**)&ws->accepts, Bp * 4},
+        {(void**)&ws->ls_rounds, Bp * 4}, {(void**)&ws->accepts, Bp * 4}, {(void**)&ws->ls_list, 2 * Bp * 4},
+        {(void**)&ws->ls_count, 5 * MAX_TRIALS * 4},
         {(void**)&ws->trace, ws->want_trace ? Bp * (size_t)d->n_iterations * 6 * 8 : 0},
         {(void**)&ws->X2, ws->split ? Bp * (N + 1) * n * 8 : 0}, {(void**)&ws->U2, ws->split ? Bp * N * m * 8 : 0},
         {(void**)&ws->CKPT, ws->split ? Bp * (size_t)ws->n_seg * n * TILE * 8 : 0},
@@ -1961,7 +1995,7 @@ int ilqr_ws_destroy(ilqr_ws* ws)
     for (auto& ev : ws->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     void* ptrs[] = {ws->X2, ws->U2, ws->CKPT, ws->LIN, ws->X, ws->U, ws->G, ws->KFB, ws->KFF, ws->XO, ws->UO, ws->INIT, ws->TARGET, ws->PARAMS, ws->WTS, ws->alphas,
                     ws->alpha_pp, ws->cost, ws->new_cost, ws->dJ, ws->trace, ws->active, ws->iters, ws->status, ws->acc_j,
-                    ws->ls_rounds, ws->accepts, ws->staging};
+                    ws->ls_rounds, ws->accepts, ws->ls_list, ws->ls_count, ws->staging};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ws->n_sub > 1) {
         if (ws->sub_start) (void)hipEventDestroy(ws->sub_start);
