@@ -11,8 +11,9 @@ from . import _lib
 from ._lib import IlqrHipError, Workspace, lib
 from .ilqr import ilqr
 from .ltvlqr import ltvlqr
+from .tracking import tracking_rollout
 from .symbolic_dynamics import (CompiledDynamics, symbolic_dynamics_acrobot, symbolic_dynamics_cartpole,
                                 symbolic_dynamics_pendulum, symbolic_dynamics_quadcopter)
 
-__all__ = ['ilqr', 'ltvlqr', 'symbolic_dynamics_pendulum', 'symbolic_dynamics_acrobot', 'symbolic_dynamics_cartpole',
+__all__ = ['ilqr', 'ltvlqr', 'tracking_rollout', 'symbolic_dynamics_pendulum', 'symbolic_dynamics_acrobot', 'symbolic_dynamics_cartpole',
            'symbolic_dynamics_quadcopter', 'CompiledDynamics', 'Workspace', 'IlqrHipError', 'lib']

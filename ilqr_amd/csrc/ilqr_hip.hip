@@ -542,6 +542,9 @@ __global__ void __launch_bounds__(64) k_backward(const KArgs a)
 // closed-loop rollout of one lane over steps [t0, t1) (ilqr.py:144-157), accumulating the input cost of
 // compute_cost; optionally storing the new trajectory (STORE) and the state at every segment boundary (CKPT).
 // ------------------------------------------------------------------------------------------------
+#ifndef CLOSED_LOOP_PREFETCH
+#define CLOSED_LOOP_PREFETCH 1
+#endif
 template <class S, bool STORE, bool CKPT>
 __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double* Xp, const double* Up, const double* Kp,
                                                     const double* kp, double* XOp, double* UOp, double* ckp,
@@ -550,61 +553,60 @@ __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double
                                                     const int t1)
 {
     constexpr int n = S::n, m = S::m;
-    // Rows of the reference trajectory and gains for step t+1 are loaded while step t computes -- in registers when the
-    // per-step record is small (n <= 4: 10 doubles), else (quadcopter: 68 doubles) the loads are left to the scheduler.
-    // Either way row t+1 of X is read before the STORE below overwrites it (in-place accept).
+    // Rows of the reference trajectory and gains for the next D steps are in flight while step t computes -- in a ring
+    // of registers when the per-step record is small (n <= 4: 10 doubles per slot), else (quadcopter: 68 doubles) only
+    // the trajectory row is one step ahead and the gains are left to the scheduler.  A slot is refilled as soon as
+    // its step's input is formed, i.e. row t+D of X is read before the STORE of row t+1 (in-place accept, D >= 1).
     constexpr bool PREFETCH = (n + 2 * m + m * n) <= 16;
+    constexpr int D = PREFETCH ? CLOSED_LOOP_PREFETCH : 1;
     double cost = 0.0;
-    double xb[n], ub[m], K[m * n], kf[m];
-    load_col<n>(Xp + (size_t)t0 * n * TILE, xb); load_col<m>(Up + (size_t)t0 * m * TILE, ub);
-    if constexpr (PREFETCH) { load_col<m * n>(Kp + (size_t)t0 * (m * n) * TILE, K); load_col<m>(kp + (size_t)t0 * m * TILE, kf); }
+    double xb[D][n], ub[D][m], K[D][m * n], kf[D][m];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int tl = t0 + d < t1 ? t0 + d : t1 - 1;
+        load_col<n>(Xp + (size_t)tl * n * TILE, xb[d]); load_col<m>(Up + (size_t)tl * m * TILE, ub[d]);
+        if constexpr (PREFETCH) { load_col<m * n>(Kp + (size_t)tl * (m * n) * TILE, K[d]); load_col<m>(kp + (size_t)tl * m * TILE, kf[d]); }
+    }
     int next_ck = CKPT ? a.ck : 0;
-    for (int t = t0; t < t1; ++t) {
-        double xb2[n], ub2[m], K2[m * n], kf2[m];
-        const int tn = t + 1 < t1 ? t + 1 : t;
-        load_col<n>(Xp + (size_t)tn * n * TILE, xb2);
-        load_col<m>(Up + (size_t)tn * m * TILE, ub2);
-        if constexpr (PREFETCH) {
-            load_col<m * n>(Kp + (size_t)tn * (m * n) * TILE, K2);
-            load_col<m>(kp + (size_t)tn * m * TILE, kf2);
-        } else {
-            load_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K);
-            load_col<m>(kp + (size_t)t * m * TILE, kf);
-        }
-        if constexpr (CKPT) {
-            if (t == next_ck) {                                                        // state entering segment t / ck
-                double* c = ckp + (size_t)(t / a.ck) * n * TILE;
+    for (int tb = t0; tb < t1; tb += D) {
 #pragma unroll
-                for (int i = 0; i < n; ++i) c[(size_t)i * TILE] = x[i];
-                next_ck += a.ck;
+        for (int d = 0; d < D; ++d) {
+            const int t = tb + d;
+            if (t >= t1) break;
+            if constexpr (!PREFETCH) {
+                load_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K[d]);
+                load_col<m>(kp + (size_t)t * m * TILE, kf[d]);
             }
-        }
-        double u[m], xn[n];
+            if constexpr (CKPT) {
+                if (t == next_ck) {                                                    // state entering segment t / ck
+                    double* c = ckp + (size_t)(t / a.ck) * n * TILE;
 #pragma unroll
-        for (int j = 0; j < m; ++j) {
-            const double ff = alpha * kf[j];                                           // :146
-            double fb = 0.0;                                                           // :147
+                    for (int i = 0; i < n; ++i) c[(size_t)i * TILE] = x[i];
+                    next_ck += a.ck;
+                }
+            }
+            double u[m], xn[n];
 #pragma unroll
-            for (int i = 0; i < n; ++i) fb = __builtin_fma(K[j * n + i], x[i] - xb[i], fb);
-            u[j] = (ub[j] + fb) + ff;                                                  // :148
-        }
-        cost = cost + input_cost<m>(u, Rk);
-        S::f(x, u, a.dt, p, xn);                                                       // :151
+            for (int j = 0; j < m; ++j) {
+                const double ff = alpha * kf[d][j];                                    // :146
+                double fb = 0.0;                                                       // :147
 #pragma unroll
-        for (int i = 0; i < n; ++i) x[i] = xn[i];
-        if constexpr (STORE) {
-            store_col<m>(UOp + (size_t)t * m * TILE, u);                               // :154
-            store_col<n>(XOp + (size_t)(t + 1) * n * TILE, x);                         // :153
-        }
+                for (int i = 0; i < n; ++i) fb = __builtin_fma(K[d][j * n + i], x[i] - xb[d][i], fb);
+                u[j] = (ub[d][j] + fb) + ff;                                           // :148
+            }
+            {
+                const int tl = t + D < t1 ? t + D : t1 - 1;                            // slot d next holds step t + D
+                load_col<n>(Xp + (size_t)tl * n * TILE, xb[d]); load_col<m>(Up + (size_t)tl * m * TILE, ub[d]);
+                if constexpr (PREFETCH) { load_col<m * n>(Kp + (size_t)tl * (m * n) * TILE, K[d]); load_col<m>(kp + (size_t)tl * m * TILE, kf[d]); }
+            }
+            cost = cost + input_cost<m>(u, Rk);
+            S::f(x, u, a.dt, p, xn);                                                   // :151
 #pragma unroll
-        for (int i = 0; i < n; ++i) xb[i] = xb2[i];
-#pragma unroll
-        for (int j = 0; j < m; ++j) ub[j] = ub2[j];
-        if constexpr (PREFETCH) {
-#pragma unroll
-            for (int j = 0; j < m; ++j) kf[j] = kf2[j];
-#pragma unroll
-            for (int i = 0; i < m * n; ++i) K[i] = K2[i];
+            for (int i = 0; i < n; ++i) x[i] = xn[i];
+            if constexpr (STORE) {
+                store_col<m>(UOp + (size_t)t * m * TILE, u);                           // :154
+                store_col<n>(XOp + (size_t)(t + 1) * n * TILE, x);                     // :153
+            }
         }
     }
     return cost;
@@ -904,6 +906,9 @@ __device__ __forceinline__ void load_lin(const double* l, double (&A)[S::n * S::
     }
 }
 
+#ifndef RICCATI_PREFETCH
+#define RICCATI_PREFETCH 4
+#endif
 template <class S>
 __global__ void __launch_bounds__(64) k_riccati(const KArgs a)
 {
@@ -926,28 +931,33 @@ __global__ void __launch_bounds__(64) k_riccati(const KArgs a)
     terminal_value<S>(Xp + (size_t)a.N * n * TILE, target, Vxx, Vx);
     double ecr = 0.0, ecr_g = 0.0, ecr_h = 0.0;
     bool ok = true;
-    double A[n * n], Bm[n * m], u[m];
-    load_lin<S>(Lp + (size_t)(a.N - 1) * Lin<S>::n_lin * TILE, A, Bm);
-    load_col<m>(Up + (size_t)(a.N - 1) * m * TILE, u);
-    for (int t = a.N - 1; t >= 0; --t) {                                               // :82
-        double A2[n * n], B2[n * m], u2[m];                                            // prefetch step t-1
-        const int tp = t > 0 ? t - 1 : 0;
-        load_lin<S>(Lp + (size_t)tp * Lin<S>::n_lin * TILE, A2, B2);
-        load_col<m>(Up + (size_t)tp * m * TILE, u2);
-        double k[m], K[m * n], g, h;
-        ok = Riccati<S>::step(A, Bm, u, Qk, Rk, a.quu_reg, Vx, Vxx, k, K, g, h) && ok;
-        if (act) {
-            store_col<m>(kp + (size_t)t * m * TILE, k);                                // :111
-            store_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K);                      // :112
+    // A_t, B_t, u_t of the next D steps are in flight while step t computes: one step (~0.5 us of dependent arithmetic)
+    // is shorter than an HBM round trip, and one wave per SIMD has nothing else to hide it behind.
+    constexpr int D = Lin<S>::n_lin + m <= 16 ? RICCATI_PREFETCH : 1;
+    double Ar[D][n * n], Br[D][n * m], ur[D][m];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int tl = a.N - 1 - d > 0 ? a.N - 1 - d : 0;
+        load_lin<S>(Lp + (size_t)tl * Lin<S>::n_lin * TILE, Ar[d], Br[d]);
+        load_col<m>(Up + (size_t)tl * m * TILE, ur[d]);
+    }
+    for (int t0 = a.N - 1; t0 >= 0; t0 -= D) {                                         // :82
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int t = t0 - d;
+            if (t < 0) break;
+            double k[m], K[m * n], g, h;
+            ok = Riccati<S>::step(Ar[d], Br[d], ur[d], Qk, Rk, a.quu_reg, Vx, Vxx, k, K, g, h) && ok;
+            const int tl = t - D > 0 ? t - D : 0;                                      // slot d next holds step t - D
+            load_lin<S>(Lp + (size_t)tl * Lin<S>::n_lin * TILE, Ar[d], Br[d]);
+            load_col<m>(Up + (size_t)tl * m * TILE, ur[d]);
+            if (act) {
+                store_col<m>(kp + (size_t)t * m * TILE, k);                            // :111
+                store_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K);                  // :112
+            }
+            const double cur = g + h;                                                  // :117
+            ecr_g += g; ecr_h += h; ecr += cur;                                        // :119-121
         }
-        const double cur = g + h;                                                      // :117
-        ecr_g += g; ecr_h += h; ecr += cur;                                            // :119-121
-#pragma unroll
-        for (int i = 0; i < n * n; ++i) A[i] = A2[i];
-#pragma unroll
-        for (int i = 0; i < n * m; ++i) Bm[i] = B2[i];
-#pragma unroll
-        for (int j = 0; j < m; ++j) u[j] = u2[j];
     }
     if (act) backward_epilogue(a, tile, lane, b, ecr, ecr_g, ecr_h, ok);
 }

@@ -96,7 +96,10 @@ int ilqr_backward_batched(const ilqr_desc* d, const double* states, const double
                           double* dJ, int32_t* status);
 
 /* ilqr.forwards_pass(learning_rate): python/ilqr.py:137-158.  learning_rate (B).  Rk/QT/target/cost may all be NULL;
- * when given, cost (B) = compute_cost(new states, new inputs). */
+ * when given, cost (B) = compute_cost(new states, new inputs).
+ * Also the closed-loop tracking simulation of python/example_acrobot_swingup_ltvlqr_tracking.py:47-67 and
+ * python/example_pendulum_swingup_ltvlqr_tracking.py:61-81 (u = inputs[i] + K[i] @ (x - states[i]), row 0 = the perturbed
+ * initial state): call with k = 0, K = the ltvlqr gains and d->zero_first_state = 0 (ilqr_amd.tracking_rollout). */
 int ilqr_forward_batched(const ilqr_desc* d, const double* init_state, const double* ref_states, const double* ref_inputs,
                          const double* k, const double* K, const double* learning_rate, const double* params,
                          double* states, double* inputs, const double* Rk, const double* QT, const double* target,

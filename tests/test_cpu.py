@@ -91,6 +91,19 @@ def test_oracle_ltvlqr(oracle):
     assert np.allclose(K[999, 0], [-1.95999848, -40.0], atol=1e-7)
 
 
+@pytest.mark.parametrize('system', ['acrobot', 'pendulum'])
+def test_oracle_tracking_rollout(oracle, system):
+    """closed-loop tracking simulation of the *_ltvlqr_tracking.py examples = forwards_pass with k = 0 and
+    row 0 written: example_acrobot_swingup_ltvlqr_tracking.py:47-67, example_pendulum_swingup_ltvlqr_tracking.py:61-81"""
+    t, l = golden(system + '_tracking'), golden(system + '_ltvlqr')
+    ref = golden('acrobot_csv') if system == 'acrobot' else l
+    for b in range(t['init'].shape[0]):
+        xs, us = oracle.forward(system, t['init'][b], ref['states'], ref['inputs'], np.zeros_like(ref['inputs']), l['K'], 0.0,
+                                float(l['dt']), l['params'], zero_first=False)
+        assert np.array_equal(xs[0], t['init'][b])
+        assert rel_err(xs, t['states'][b]) < 1e-12 and rel_err(us, t['inputs'][b]) < 1e-12
+
+
 def test_acrobot_csv_is_the_reference_solve_output():
     """the reference's committed CSVs (written in 2021) vs the reference re-run today (fixture): 1.3e-10 apart"""
     csv, g = golden('acrobot_csv'), golden('acrobot_solve')

@@ -311,6 +311,53 @@ def test_ltvlqr_vs_oracle_batch(amd, oracle):
         assert rel_err(K[b], Ko[b]) < TOL
 
 
+# ------------------------------------------------------------------------------------------ tracking
+@pytest.mark.parametrize('system', ['acrobot', 'pendulum'])
+def test_tracking_rollout_examples(amd, system):
+    """the perturbed closed-loop simulations of the two *_ltvlqr_tracking.py examples, one by one and as a batch"""
+    t, l = golden(system + '_tracking'), golden(system + '_ltvlqr')
+    ref = golden('acrobot_csv') if system == 'acrobot' else l
+    f = dyn(amd, system)[0]
+    dt = float(l['dt'])
+    xs, us = amd.tracking_rollout(ref['states'], ref['inputs'], l['K'], f, t['init'][0], dt, l['params'])
+    assert xs.shape == ref['states'].shape and us.shape == ref['inputs'].shape
+    assert np.array_equal(xs[0], t['init'][0])                      # row 0 is the perturbed state (no quirk Q1 here)
+    assert rel_err(xs, t['states'][0]) < TOL and rel_err(us, t['inputs'][0]) < TOL
+    XS, US = amd.tracking_rollout(ref['states'], ref['inputs'], l['K'], f, t['init'], dt, l['params'])
+    for b in range(t['init'].shape[0]):
+        assert rel_err(XS[b], t['states'][b]) < TOL and rel_err(US[b], t['inputs'][b]) < TOL
+    assert np.array_equal(XS[0], xs) and np.array_equal(US[0], us)
+
+
+def test_gain_schedule_then_tracking_resident(amd, oracle):
+    """ltvlqr and the tracking simulation chained in HBM (no host round trip of K): Workspace.ltvlqr -> Workspace.forward"""
+    from ilqr_amd import _lib
+    csv, g = golden('acrobot_csv'), golden('acrobot_ltvlqr')
+    rng = np.random.default_rng(3)
+    B, N = 70, 500
+    states = np.repeat(csv['states'][None, :N + 1], B, axis=0)
+    inputs = np.repeat(csv['inputs'][None, :N], B, axis=0)
+    init = np.array([-np.pi / 2, 0, 0, 0]) + rng.uniform(-np.pi / 8, np.pi / 8, (B, 4)) * np.array([1, 1, 0.2, 0.2])
+    dt = float(g['dt'])
+    with _lib.Workspace('acrobot', N, B, dt, zero_first_state=False) as ws:
+        ws.set_weights(g['Qk'], g['Rk'], g['QT'])
+        ws.upload(_lib.F_PARAMS, g['params'])
+        ws.upload(_lib.F_STATES, states)
+        ws.upload(_lib.F_INPUTS, inputs)
+        ws.upload(_lib.F_INIT, init)
+        ws.upload(_lib.F_ALPHA, np.zeros(B))
+        ws.ltvlqr()
+        ws.forward(with_cost=False)
+        ws.sync()
+        K = ws.download(_lib.F_KFB)
+        xs, us = ws.download(_lib.F_STATES_OUT), ws.download(_lib.F_INPUTS_OUT)
+    Ko = oracle.ltvlqr_batched('acrobot', states, inputs, g['Qk'], g['Rk'], g['QT'], dt, g['params'])
+    for b in range(0, B, 7):
+        assert rel_err(K[b], Ko[b]) < TOL
+        xo, uo = oracle.forward('acrobot', init[b], states[b], inputs[b], np.zeros((N, 1)), Ko[b], 0.0, dt, g['params'], zero_first=False)
+        assert rel_err(xs[b], xo) < TOL and rel_err(us[b], uo) < TOL
+
+
 # ------------------------------------------------------------------------------------------ API behaviour
 def test_errors_are_reported_not_thrown(amd):
     from ilqr_amd import _lib

@@ -16,6 +16,8 @@ Fixtures (all float64, reference numpy layout):
   <sys>_solve.npz          full ilqr.solve() of the example config + per-iteration trace + Armijo ratios
   <sys>_passes.npz         teacher-forced single passes on the initial rollout (backward; forward at 3 alphas)
   <sys>_ltvlqr.npz         ltvlqr gains (acrobot: on the CSV trajectory; pendulum: on its solve() output)
+  <sys>_tracking.npz       the closed-loop simulation the two *_ltvlqr_tracking.py examples run with those gains from a
+                           perturbed initial state (their own perturbation + a few seeded ones), reference f
   <sys>_batch.npz          8 seeded problems, short horizon, n_iterations=3, solved one by one
 """
 import contextlib
@@ -267,6 +269,30 @@ def gen_batch(name, fab, B=8):
     save(name + '_batch', **out)
 
 
+def track(f, states, inputs, K, x0, dt, p):
+    """What example_acrobot_swingup_ltvlqr_tracking.py:47-67 / example_pendulum_swingup_ltvlqr_tracking.py:61-81 simulate:
+    u = inputs[i] + K[i] @ (x - states[i]), x <- f(x, u); row 0 of the output is the perturbed initial state."""
+    xs, us = states.copy(), inputs.copy()
+    x = np.array(x0, dtype=float)
+    xs[0, :] = x
+    for i in range(inputs.shape[0]):
+        err = (x - states[i, :]).flatten()
+        u = inputs[i, :] + K[i, :, :] @ err
+        x = f(x, u, dt, p).flatten()
+        xs[i + 1, :] = x
+        us[i, :] = u
+    return xs, us
+
+
+def gen_tracking(name, f, states, inputs, K, init, example_perturbation, dt, p):
+    rng = np.random.default_rng(7)
+    perts = [np.asarray(example_perturbation, float), np.zeros(len(init))]
+    perts += [0.3 * example_perturbation[0] * rng.standard_normal(len(init)) for _ in range(4)]
+    x0 = np.stack([np.asarray(init, float) + d for d in perts])
+    outs = [track(f, states, inputs, K, x, dt, p) for x in x0]
+    save(name + '_tracking', init=x0, states=np.stack([o[0] for o in outs]), inputs=np.stack([o[1] for o in outs]))
+
+
 def gen_ltvlqr(fabs, pend_solve):
     # acrobot: example_acrobot_swingup_ltvlqr_tracking.py:26-45
     states = np.loadtxt(os.path.join(REF, 'acrobot_swingup_states.csv'), dtype=float, delimiter=',')
@@ -278,6 +304,7 @@ def gen_ltvlqr(fabs, pend_solve):
     _, A, B = fabs['acrobot']
     K = ref_ltvlqr(states, inputs, A, B, Qk, Rk, QT, 0.001, p)
     save('acrobot_ltvlqr', Qk=Qk, Rk=Rk, QT=QT, params=p.astype(float), dt=np.float64(0.001), K=K)
+    gen_tracking('acrobot', fabs['acrobot'][0], states, inputs, K, [-np.pi / 2, 0, 0, 0], np.array([-np.pi / 8, 0, 0, 0]), 0.001, p)
     # pendulum: example_pendulum_swingup_ltvlqr_tracking.py:53-59 on the solve() output
     Qk, Rk, QT = 0.1 * np.eye(2), 0.01 * np.eye(1), 100 * np.eye(2)
     p = np.array([1, 9.8, 1])
@@ -285,6 +312,8 @@ def gen_ltvlqr(fabs, pend_solve):
     K = ref_ltvlqr(pend_solve['states'], pend_solve['inputs'], A, B, Qk, Rk, QT, 0.005, p)
     save('pendulum_ltvlqr', Qk=Qk, Rk=Rk, QT=QT, params=p.astype(float), dt=np.float64(0.005), K=K,
          states=pend_solve['states'], inputs=pend_solve['inputs'])
+    gen_tracking('pendulum', fabs['pendulum'][0], pend_solve['states'], pend_solve['inputs'], K, [0, 0],
+                 np.array([-np.pi / 4, 0]), 0.005, p)
 
 
 def main():
@@ -293,6 +322,10 @@ def main():
     for name in models.BUILDERS:
         fabs[name] = lambdified(name)
     print('writing fixtures to', OUT)
+    if only == {'tracking'}:          # only the tracking simulations, from the trajectories already in tests/golden
+        pl = np.load(os.path.join(OUT, 'pendulum_ltvlqr.npz'))
+        gen_ltvlqr(fabs, dict(states=pl['states'], inputs=pl['inputs']))
+        return
     gen_mat_kats()
     solves = {}
     for name in models.BUILDERS:
