@@ -906,6 +906,9 @@ __device__ __forceinline__ void load_lin(const double* l, double (&A)[S::n * S::
     }
 }
 
+#ifndef RICCATI_GRP_WAVES
+#define RICCATI_GRP_WAVES 1
+#endif
 #ifndef RICCATI_PREFETCH
 #define RICCATI_PREFETCH 4
 #endif
@@ -1004,7 +1007,7 @@ __device__ __forceinline__ int lin_index(const int e)
 }
 
 template <class S>
-__global__ void __launch_bounds__(64) k_riccati_grp(const KArgs a)
+__global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KArgs a)
 {
     using G = Grp<S>;
     constexpr int n = S::n, m = S::m, GL = G::GL, P = G::P, NL = Lin<S>::n_lin, LD = G::LD, KA = G::KA, KB = G::KB;

@@ -118,6 +118,41 @@ def declared_symbols():
     return sorted(set(re.findall(r'\b((?:ilqr|ltvlqr)_[a-z_0-9]+)\s*\(', text)))
 
 
+def test_trajectory_files_in_the_reference_formats(tmp_path):
+    """the CSV pair of example_acrobot_swingup.py:56-57 / ..._ltvlqr_tracking.py:26-28 and the .mat field
+    set of matlab/smooth-ilqr/example_{pendulum,acrobot,cartpole}.m (shapes as in the reference's *-trajectory.mat)"""
+    import ilqr_amd
+    csv, g = golden('acrobot_csv'), golden('acrobot_ltvlqr')
+    stem = str(tmp_path / 'acrobot_swingup')
+    (ps, pi), = ilqr_amd.save_trajectory_csv(stem, csv['states'], csv['inputs'])
+    assert ps.endswith('acrobot_swingup_states.csv') and pi.endswith('acrobot_swingup_inputs.csv')
+    first = open(ps).readline().strip().split(',')
+    assert len(first) == 4 and first[0] == '%.18e' % csv['states'][0, 0]            # np.savetxt's default format
+    s2, u2 = ilqr_amd.load_trajectory_csv(stem)
+    assert np.array_equal(s2, csv['states']) and np.array_equal(u2, csv['inputs']) and u2.shape == (3000, 1)
+    # the reference's own reader (loadtxt + reshape, ..._ltvlqr_tracking.py:26-28) sees the same arrays
+    assert np.array_equal(np.loadtxt(ps, dtype=float, delimiter=','), csv['states'])
+    # batch -> one pair per problem
+    paths = ilqr_amd.save_trajectory_csv(str(tmp_path / 'b'), np.stack([csv['states'][:11]] * 3), np.stack([csv['inputs'][:10]] * 3))
+    assert len(paths) == 3 and paths[2][0].endswith('b_00002_states.csv')
+    assert np.array_equal(ilqr_amd.load_trajectory_csv(str(tmp_path / 'b'), 2)[1], csv['inputs'][:10])
+    # .mat
+    import scipy.io
+    mp = str(tmp_path / 'acrobot-swingup-trajectory.mat')
+    ilqr_amd.save_trajectory_mat(mp, csv['states'], csv['inputs'], float(g['dt']), g['params'], K_feedback=g['K'],
+                                 target_state=[np.pi / 2, 0, 0, 0])
+    raw = scipy.io.loadmat(mp)
+    assert raw['states'].shape == (3001, 4) and raw['inputs'].shape == (3000, 1) and raw['dt'].shape == (1, 1)
+    assert raw['parameters'].shape == (1, 5) and raw['K_feedback'].shape == (3000, 1, 4) and raw['target_state'].shape == (4, 1)
+    d = ilqr_amd.load_trajectory_mat(mp)
+    assert d['dt'] == float(g['dt']) and np.array_equal(d['K_feedback'], g['K']) and d['parameters'].shape == (5,)
+    assert np.array_equal(d['states'], csv['states']) and d['target_state'].shape == (4,)
+    ref_mat = '/root/reference/matlab/smooth-ilqr/cartpole-swingup-trajectory.mat'    # build container only
+    if os.path.exists(ref_mat):
+        r = ilqr_amd.load_trajectory_mat(ref_mat)
+        assert r['states'].shape == (1002, 4) and r['K_feedback'].shape == (1001, 1, 4) and r['dt'] == 0.005
+
+
 def test_library_exports_every_declared_symbol():
     """loads libilqr_hip.so without a GPU and resolves every function include/ilqr_hip.h declares"""
     from ilqr_amd import _lib
