@@ -629,11 +629,17 @@ __device__ __forceinline__ double closed_loop(const KArgs& a, const double* Xp, 
 // (64/W problems per wave); the accepted trial is the FIRST j whose Armijo ratio passes (:193), found with a
 // ballot over the lane group -- not the lowest cost.  Rounds of W trials repeat until accepted or exhausted.
 // ------------------------------------------------------------------------------------------------
-template <class S, int W, bool CKPT>
-#ifndef LS_WAVES_PER_EU
-#define LS_WAVES_PER_EU 2
+// register budget of the line search = 512 / (waves per SIMD): what each system's time step needs without spilling
+#ifndef LS_WAVES_SMALL
+#define LS_WAVES_SMALL 2
 #endif
-__global__ void __launch_bounds__(W == 64 ? 512 : 256, (S::n <= 4 ? LS_WAVES_PER_EU : 1)) k_linesearch(const KArgs a)
+template <class S>
+constexpr int ls_waves_per_simd()
+{
+    return S::n > 4 ? 1 : (S::id == ILQR_DYN_ACROBOT_ID ? 2 : LS_WAVES_SMALL);   // (4 for cartpole spills 14 VGPRs and gains nothing)
+}
+template <class S, int W, bool CKPT>
+__global__ void __launch_bounds__(W == 64 ? 512 : 256, ls_waves_per_simd<S>()) k_linesearch(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
     constexpr int G = TILE / W;
