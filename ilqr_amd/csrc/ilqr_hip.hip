@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/ilqr_hip.h"
@@ -913,7 +914,7 @@ __device__ __forceinline__ void load_lin(const double* l, double (&A)[S::n * S::
 }
 
 #ifndef RICCATI_GRP_WAVES
-#define RICCATI_GRP_WAVES 1
+#define RICCATI_GRP_WAVES 2
 #endif
 #ifndef RICCATI_PREFETCH
 #define RICCATI_PREFETCH 4
@@ -972,28 +973,29 @@ __global__ void __launch_bounds__(64) k_riccati(const KArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_riccati_grp: the same recursion as k_riccati with a GROUP of GL lanes per problem (64/GL problems per wave),
-// for systems whose V_xx does not fit one lane's registers (n = 12: V_xx, Q_xx and A^T V_xx are 3 x 144 doubles).
-//   * between steps lane j of a group holds COLUMN j of V_xx and V_x[j];
-//   * column phase: (A^T V_xx)[:, j] and (B^T V_xx)[:, j] from the lane's own column -- the sums run over the
-//     structural non-zeros of A / B, identical code for every lane; the Jacobian entries are read from LDS where the
-//     group staged the step's LIN row (dense, expanded through a per-lane index map);
-//   * transpose through LDS (padded rows, conflict free); row phase: lane i forms row i of Q_xx = (A^T V_xx) A,
-//     column i of Q_ux and K, Q_x[i]; Q_uu, Q_u, the inverse and k are small and computed by every lane;
-//   * Q_ux and K are shared through LDS for the four-term V_xx update of row i (ilqr.py:125), then rows -> columns.
+// k_riccati_grp: the same recursion as k_riccati with a ROW of 16 lanes per problem (4 problems per wave), for
+// systems whose V_xx does not fit one lane's registers (n = 12: V_xx, Q_xx and A^T V_xx are 3 x 144 doubles).
+//   * lane r of a row keeps ROW r of A_t and of B_t in registers (gathered straight from LIN, next step in flight);
+//     between steps lane j holds COLUMN j of V_xx and V_x[j].
+//   * every product needs one operand that is the same for the whole row of lanes (A[r][i], K[l][j], V_x[r], ...).
+//     Those are never staged in LDS: the DPALU broadcast `v_fmac_f64_dpp ... row_newbcast:r` multiplies lane r's
+//     register into every lane of its row inside the FMA itself.  (The first version read them from LDS: 262 LDS
+//     instructions per step, and the CU's single LDS pipe -- shared by the four SIMDs -- was the bound, VALU 33 % busy.)
+//   * column phase (lane j): (A^T V_xx)[:, j], (B^T V_xx)[:, j] over the structural non-zeros; three small LDS
+//     transposes remain (A^T V_xx columns -> rows, A rows -> columns for Q_ux / Q_x, new V_xx rows -> columns);
+//   * row phase (lane i): row i of Q_xx = (A^T V_xx) A and of the four-term V_xx update (ilqr.py:125), column i of
+//     Q_ux and K, Q_x[i]; Q_uu, Q_u, the inverse and k are small and computed by every lane.
 // One wave per workgroup: the LDS hand-offs are ordered by program order (the barriers only pin the compiler).
 // Operation order follows the reference ((A^T V) A, (B^T V) A, ...), as Riccati<S>::step does.
 // ------------------------------------------------------------------------------------------------
 template <class S>
 struct Grp {
     static constexpr int n = S::n, m = S::m;
-    static constexpr int GL = n <= 2 ? 2 : (n <= 4 ? 4 : (n <= 8 ? 8 : 16));
+    static constexpr int GL = 16;                       // one DPP row
     static constexpr int P = TILE / GL;                 // problems per wave
-    static constexpr int KA = (n * n + GL - 1) / GL;    // dense A entries staged per lane
-    static constexpr int KB = (n * m + GL - 1) / GL;
-    static constexpr int LD = n + 1;                    // padded leading dimension of the transpose buffer
-    static constexpr int oA = 0, oB = oA + n * n, oT = oB + n * m, oBtV = oT + n * LD, oQux = oBtV + m * n,
-                         oK = oQux + m * n, oVx = oK + m * n, oU = oVx + n, SLOT = ((oU + m + 1) | 1);
+    static constexpr int LD = n + 1;                    // padded leading dimension of the transpose buffers
+    static constexpr int oT = 0, oAT = oT + n * LD, SLOT = ((oAT + n * LD + 1) | 1);
+    static_assert(n <= GL, "k_riccati_grp: one lane per state");
 };
 
 // index of dense entry e of A (or B) in the step's LIN row; -1 structural zero, -2 structural one
@@ -1012,15 +1014,42 @@ __device__ __forceinline__ int lin_index(const int e)
     return res;
 }
 
+// acc += (lane L of this lane's 16-lane row of `src`) * own.  The wait states a DPP read of a just-written VGPR needs
+// are not inserted around inline asm by the compiler, hence the s_nop.
+template <int L>
+__device__ __forceinline__ void fmac_row(double& acc, const double src, const double own)
+{
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(own), "n"(L));
+}
+template <int L>
+__device__ __forceinline__ double bcast_row(const double src)
+{
+    double r;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(L));
+    return r;
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 template <class S>
 __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KArgs a)
 {
     using G = Grp<S>;
-    constexpr int n = S::n, m = S::m, GL = G::GL, P = G::P, NL = Lin<S>::n_lin, LD = G::LD, KA = G::KA, KB = G::KB;
-    __shared__ double sh[P * G::SLOT];
+    constexpr int n = S::n, m = S::m, GL = G::GL, P = G::P, NL = Lin<S>::n_lin, LD = G::LD;
+    __shared__ double sh[P * G::SLOT + n * n];
     const int lane = threadIdx.x;
     const int grp = lane / GL, c = lane % GL;
-    const long long b = a.tile0 * TILE + (long long)blockIdx.x * P + grp;
+    // The 16 workgroups of a tile touch the same 128-byte lines (4 problems = 32 bytes of each): workgroups are dealt
+    // round-robin over the 8 XCDs, so logical ids are chosen such that a tile's workgroups share one XCD's L2.
+    const unsigned pb = blockIdx.x, nb8 = gridDim.x & ~7u;
+    const unsigned lb = pb < nb8 ? (pb & 7u) * (nb8 >> 3) + (pb >> 3) : pb;
+    const long long b = a.tile0 * TILE + (long long)lb * P + grp;
     const long long tile = b >> 6;
     const int pl = (int)(b & 63);
     const bool act = a.active[b] != 0;
@@ -1028,15 +1057,25 @@ __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KAr
     double* s = sh + grp * G::SLOT;
     const bool row = c < n;
     const int cc = row ? c : n - 1;                     // surplus lanes shadow the last row / column and never store
-    // per-lane staging map
-    int aidx[KA], bidx[KB];
+    // where row cc of A_t / B_t sits in a LIN record: byte offsets of the general entries (structural zeros and ones
+    // load a harmless valid entry instead; their constants are written to the transpose buffer once, below)
+    int aoff[n], boff[m];
+    unsigned amask = 0;
 #pragma unroll
-    for (int q = 0; q < KA; ++q) aidx[q] = (c + GL * q) < n * n ? lin_index<S, false>(c + GL * q) : -1;
+    for (int i = 0; i < n; ++i) {
+        const int q = lin_index<S, false>(cc * n + i);
+        aoff[i] = (q > 0 ? q : 0) * (TILE * (int)sizeof(double));
+        amask |= (q >= 0 ? 1u : 0u) << i;
+        if (row && q < 0) s[G::oAT + i * LD + c] = q == -2 ? 1.0 : 0.0;
+    }
 #pragma unroll
-    for (int q = 0; q < KB; ++q) bidx[q] = (c + GL * q) < n * m ? lin_index<S, true>(c + GL * q) : -1;
-    double Qkr[n], Rk[m * m], Vc[n], vx;
-#pragma unroll
-    for (int j = 0; j < n; ++j) Qkr[j] = a.WTS[cc * n + j];                            // row i of Q_k
+    for (int l = 0; l < m; ++l) {
+        const int q = lin_index<S, true>(cc * m + l);
+        boff[l] = (q > 0 ? q : 0) * (TILE * (int)sizeof(double));
+    }
+    double Rk[m * m], Vc[n], vx;
+    double* sQk = sh + P * G::SLOT;                                                    // Q_k, shared by the rows
+    for (int e = lane; e < n * n; e += TILE) sQk[e] = a.WTS[e];
     load_uniform<m * m>(a.WTS + n * n, Rk);
     const double* QT = a.WTS + n * n + m * m;
 #pragma unroll
@@ -1055,106 +1094,141 @@ __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KAr
         for (int q = 0; q < n; ++q) acc = __builtin_fma(QT[cc * n + q], xN[q] - target[q], acc);
         vx = acc;
     }
-    double stA[KA], stB[KB], stU;
-    auto load_stage = [&](const int t) {
-        const double* l = Lp + (size_t)t * NL * TILE;
+    auto load_rows = [&](int t, double (&Ar)[n], double (&Br)[m], double (&u)[m]) {
+        const char* l = (const char*)(Lp + (size_t)t * NL * TILE);
 #pragma unroll
-        for (int q = 0; q < KA; ++q) stA[q] = aidx[q] >= 0 ? l[(size_t)aidx[q] * TILE] : (aidx[q] == -2 ? 1.0 : 0.0);
+        for (int i = 0; i < n; ++i) {
+            int o = aoff[i];
+            asm volatile("" : "+v"(o));                  // keep base + offset out of the loop-invariant (spilled) set
+            Ar[i] = *(const double*)(l + o);
+        }
 #pragma unroll
-        for (int q = 0; q < KB; ++q) stB[q] = bidx[q] >= 0 ? l[(size_t)bidx[q] * TILE] : (bidx[q] == -2 ? 1.0 : 0.0);
-        stU = c < m ? Up[((size_t)t * m + c) * TILE] : 0.0;
+        for (int q = 0; q < m; ++q) {
+            int o = boff[q];
+            asm volatile("" : "+v"(o));
+            Br[q] = *(const double*)(l + o);
+        }
+#pragma unroll
+        for (int q = 0; q < m; ++q) u[q] = Up[((size_t)t * m + q) * TILE];
     };
-    load_stage(a.N - 1);
     double ecr = 0.0, ecr_g = 0.0, ecr_h = 0.0;
     bool ok = true;
-    for (int t = a.N - 1; t >= 0; --t) {                                               // :82
-        // ---- stage A_t, B_t, u_t and V_x into LDS
-#pragma unroll
-        for (int q = 0; q < KA; ++q) if (c + GL * q < n * n) s[G::oA + c + GL * q] = stA[q];
-#pragma unroll
-        for (int q = 0; q < KB; ++q) if (c + GL * q < n * m) s[G::oB + c + GL * q] = stB[q];
-        if (c < m) s[G::oU + c] = stU;
-        if (row) s[G::oVx + c] = vx;
-        __syncthreads();
-        load_stage(t > 0 ? t - 1 : 0);                                                 // prefetch the next step's row
+    __syncthreads();
+    // one time step with rows (Ar, Br, u) of step t in registers; the rows of step t-1 are requested into (An, Bn, un)
+    auto step = [&](const int t, const double (&Ar)[n], const double (&Br)[m], const double (&u)[m], double (&An)[n],
+                    double (&Bn)[m], double (&un)[m]) {
+        load_rows(t > 0 ? t - 1 : 0, An, Bn, un);
         // ---- column phase (lane j): A^T V_xx and B^T V_xx, column j
         double AtV[n], BtV[m];
 #pragma unroll
-        for (int i = 0; i < n; ++i) {
-            double acc = 0.0; bool first = true;
+        for (int i = 0; i < n; ++i) AtV[i] = 0.0;
 #pragma unroll
-            for (int r = 0; r < n; ++r) acc_term(acc, first, S::a_kind(r * n + i), s[G::oA + r * n + i], Vc[r]);
-            AtV[i] = acc;
-        }
-#pragma unroll
-        for (int l = 0; l < m; ++l) {
-            double acc = 0.0; bool first = true;
-#pragma unroll
-            for (int r = 0; r < n; ++r) acc_term(acc, first, S::b_kind(r * m + l), s[G::oB + r * m + l], Vc[r]);
-            BtV[l] = acc;
-        }
+        for (int l = 0; l < m; ++l) BtV[l] = 0.0;
+        static_for<0, n>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            static_for<0, n>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr char kd = S::A_pat[r * n + i];
+                if constexpr (kd == 'x') fmac_row<r>(AtV[i], Ar[i], Vc[r]);            // A[r][i] * V[r][j]
+                else if constexpr (kd == '1') AtV[i] = AtV[i] + Vc[r];
+            });
+            static_for<0, m>([&](auto lc) {
+                constexpr int l = decltype(lc)::value;
+                constexpr char kd = S::B_pat[r * m + l];
+                if constexpr (kd == 'x') fmac_row<r>(BtV[l], Br[l], Vc[r]);            // B[r][l] * V[r][j]
+                else if constexpr (kd == '1') BtV[l] = BtV[l] + Vc[r];
+            });
+        });
         if (row) {
 #pragma unroll
-            for (int i = 0; i < n; ++i) s[G::oT + i * LD + c] = AtV[i];
-#pragma unroll
-            for (int l = 0; l < m; ++l) s[G::oBtV + l * n + c] = BtV[l];
+            for (int i = 0; i < n; ++i) {
+                s[G::oT + i * LD + c] = AtV[i];
+                if ((amask >> i) & 1u) s[G::oAT + i * LD + c] = Ar[i];
+            }
         }
         __syncthreads();
-        // ---- row phase (lane i)
-        double Ri[n], Qxx[n], Qux[m], Quu[m * m], Quu_inv[m * m], Qu[m], u[m], k[m], Kc[m];
+        // ---- gains (every lane: Q_uu, Q_u, the inverse, k; lane i: column i of Q_ux and K, Q_x[i]).  Done before the
+        // row phase so that Q_uu and its inverse (2 m^2 doubles) are dead when the rows of A^T V_xx come into registers.
+        double Qux[m], Qu[m], k[m], Kc[m], KtQuu[m], g = 0.0, h = 0.0;
+        {
+            double Quu[m * m], Quu_inv[m * m], Acol[n], Qx = 0.0;
 #pragma unroll
-        for (int r = 0; r < n; ++r) Ri[r] = s[G::oT + cc * LD + r];                    // (A^T V_xx)[i][:]
+            for (int r = 0; r < n; ++r) Acol[r] = s[G::oAT + cc * LD + r];             // A[r][i]
 #pragma unroll
-        for (int j = 0; j < n; ++j) {                                                  // :103 row i of Q_xx
-            double acc = 0.0; bool first = true;
+            for (int q = 0; q < m * m; ++q) Quu[q] = 0.0;
 #pragma unroll
-            for (int r = 0; r < n; ++r) acc_term(acc, first, S::a_kind(r * n + j), s[G::oA + r * n + j], Ri[r]);
-            Qxx[j] = Qkr[j] + acc;
-        }
+            for (int l = 0; l < m; ++l) Qu[l] = 0.0;
 #pragma unroll
-        for (int l = 0; l < m; ++l) {                                                  // :101 column i of Q_ux (dense in r)
-            double acc = 0.0;
+            for (int l = 0; l < m; ++l) Qux[l] = 0.0;
+            static_for<0, n>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                static_for<0, m>([&](auto l2c) {
+                    constexpr int l2 = decltype(l2c)::value;
+                    constexpr char kd = S::B_pat[r * m + l2];
+                    if constexpr (kd == 'x') {
+                        const double Brl = bcast_row<r>(Br[l2]);                       // B[r][l2], the same in every lane
 #pragma unroll
-            for (int r = 0; r < n; ++r) acc = __builtin_fma(s[G::oBtV + l * n + r], s[G::oA + r * n + cc], acc);
-            Qux[l] = acc;
-        }
+                        for (int l = 0; l < m; ++l) fmac_row<r>(Quu[l * m + l2], BtV[l], Brl);       // :102
+                        fmac_row<r>(Qu[l2], vx, Brl);                                  // :100 B[r][l2] * V_x[r]
+                    } else if constexpr (kd == '1') {
 #pragma unroll
-        for (int l = 0; l < m; ++l) {                                                  // :102 Q_uu (every lane)
+                        for (int l = 0; l < m; ++l) Quu[l * m + l2] = Quu[l * m + l2] + bcast_row<r>(BtV[l]);
+                        Qu[l2] = Qu[l2] + bcast_row<r>(vx);
+                    }
+                });
 #pragma unroll
-            for (int l2 = 0; l2 < m; ++l2) {
-                double acc = 0.0; bool first = true;
+                for (int l = 0; l < m; ++l) fmac_row<r>(Qux[l], BtV[l], Acol[r]);       // :101 (B^T V_xx)[l][r] * A[r][i]
+                fmac_row<r>(Qx, vx, Acol[r]);                                          // :99  A[r][i] * V_x[r]
+            });
 #pragma unroll
-                for (int r = 0; r < n; ++r) acc_term(acc, first, S::b_kind(r * m + l2), s[G::oB + r * m + l2], s[G::oBtV + l * n + r]);
-                Quu[l * m + l2] = Rk[l * m + l2] + acc;
+            for (int l = 0; l < m; ++l) {
+#pragma unroll
+                for (int l2 = 0; l2 < m; ++l2) Quu[l * m + l2] = Rk[l * m + l2] + Quu[l * m + l2];
+                Quu[l * m + l] += a.quu_reg;
             }
-            Quu[l * m + l] += a.quu_reg;
-        }
-        double Qx = 0.0;                                                               // :99 Q_x[i] (dense in r)
 #pragma unroll
-        for (int r = 0; r < n; ++r) Qx = __builtin_fma(s[G::oA + r * n + cc], s[G::oVx + r], Qx);
+            for (int l = 0; l < m; ++l) {                                              // :93 l_u = R_k u
+                double lu = 0.0;
 #pragma unroll
-        for (int l = 0; l < m; ++l) u[l] = s[G::oU + l];
-#pragma unroll
-        for (int l = 0; l < m; ++l) {                                                  // :93,:100 Q_u (every lane)
-            double lu = 0.0;
-#pragma unroll
-            for (int l2 = 0; l2 < m; ++l2) lu = __builtin_fma(Rk[l * m + l2], u[l2], lu);
-            double acc = 0.0; bool first = true;
-#pragma unroll
-            for (int r = 0; r < n; ++r) acc_term(acc, first, S::b_kind(r * m + l), s[G::oB + r * m + l], s[G::oVx + r]);
-            Qu[l] = lu + acc;
-        }
-        ok = Riccati<S>::inv_spd(Quu, Quu_inv) && ok;                                  // :106
-#pragma unroll
-        for (int l = 0; l < m; ++l) {                                                  // :107-108
-            double acc = 0.0, acc2 = 0.0;
-#pragma unroll
-            for (int l2 = 0; l2 < m; ++l2) {
-                acc = __builtin_fma(-Quu_inv[l * m + l2], Qu[l2], acc);
-                acc2 = __builtin_fma(-Quu_inv[l * m + l2], Qux[l2], acc2);
+                for (int l2 = 0; l2 < m; ++l2) lu = __builtin_fma(Rk[l * m + l2], u[l2], lu);
+                Qu[l] = lu + Qu[l];
             }
-            k[l] = acc;
-            Kc[l] = acc2;
+                ok = Riccati<S>::inv_spd(Quu, Quu_inv) && ok;                              // :106
+    #pragma unroll
+            for (int l = 0; l < m; ++l) {                                              // :107-108
+                double acc = 0.0, acc2 = 0.0;
+#pragma unroll
+                for (int l2 = 0; l2 < m; ++l2) {
+                    acc = __builtin_fma(-Quu_inv[l * m + l2], Qu[l2], acc);
+                    acc2 = __builtin_fma(-Quu_inv[l * m + l2], Qux[l2], acc2);
+                }
+                k[l] = acc;
+                Kc[l] = acc2;
+            }
+#pragma unroll
+            for (int l = 0; l < m; ++l) g = __builtin_fma(-Qu[l], k[l], g);            // :115
+#pragma unroll
+            for (int l = 0; l < m; ++l) {                                              // :116
+                double acc = 0.0;
+#pragma unroll
+                for (int l2 = 0; l2 < m; ++l2) acc = __builtin_fma(0.5 * k[l2], Quu[l2 * m + l], acc);
+                h = __builtin_fma(acc, k[l], h);
+            }
+#pragma unroll
+            for (int l = 0; l < m; ++l) {
+                double acc = 0.0;
+#pragma unroll
+                for (int l2 = 0; l2 < m; ++l2) acc = __builtin_fma(Kc[l2], Quu[l2 * m + l], acc);
+                KtQuu[l] = acc;
+            }
+            double v1 = 0.0, v2 = 0.0, v3 = 0.0;                                       // :124
+#pragma unroll
+            for (int l = 0; l < m; ++l) v1 = __builtin_fma(KtQuu[l], k[l], v1);
+#pragma unroll
+            for (int l = 0; l < m; ++l) v2 = __builtin_fma(Kc[l], Qu[l], v2);
+#pragma unroll
+            for (int l = 0; l < m; ++l) v3 = __builtin_fma(Qux[l], k[l], v3);
+            vx = ((Qx + v1) + v2) + v3;
         }
         if (act) {
             if (row) {
@@ -1164,63 +1238,45 @@ __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KAr
 #pragma unroll
             for (int l = 0; l < m; ++l) if (c == l) kp[((size_t)t * m + l) * TILE] = k[l];          // :111
         }
-        double g = 0.0, h = 0.0;                                                       // :115-116
-#pragma unroll
-        for (int l = 0; l < m; ++l) g = __builtin_fma(-Qu[l], k[l], g);
-#pragma unroll
-        for (int l = 0; l < m; ++l) {
-            double acc = 0.0;
-#pragma unroll
-            for (int l2 = 0; l2 < m; ++l2) acc = __builtin_fma(0.5 * k[l2], Quu[l2 * m + l], acc);
-            h = __builtin_fma(acc, k[l], h);
-        }
-        const double cur = g + h;
+        const double cur = g + h;                                                      // :117
         ecr_g += g; ecr_h += h; ecr += cur;                                            // :119-121
-        if (row) {
+        // ---- row phase (lane i): row i of Q_xx (:103) and of the new V_xx (:125), one entry at a time, written
+        // straight into the lane's own row of the transpose buffer (whose old contents are in Ri by then)
+        double Ri[n], Aw[n];
 #pragma unroll
-            for (int l = 0; l < m; ++l) { s[G::oQux + l * n + c] = Qux[l]; s[G::oK + l * n + c] = Kc[l]; }
-        }
-        __syncthreads();
-        // ---- value function update, row i (:124-125)
-        double KtQuu[m];
+        for (int r = 0; r < n; ++r) Ri[r] = s[G::oT + cc * LD + r];                    // (A^T V_xx)[i][:]
 #pragma unroll
-        for (int l = 0; l < m; ++l) {
+        for (int j = 0; j < n; ++j) Aw[j] = s[G::oAT + j * LD + cc];                   // own row of A_t again (its
+        static_for<0, n>([&](auto jc) {                                                // registers ended with the column phase)
+            constexpr int j = decltype(jc)::value;
             double acc = 0.0;
-#pragma unroll
-            for (int l2 = 0; l2 < m; ++l2) acc = __builtin_fma(Kc[l2], Quu[l2 * m + l], acc);
-            KtQuu[l] = acc;
-        }
-        {
-            double v1 = 0.0, v2 = 0.0, v3 = 0.0;
-#pragma unroll
-            for (int l = 0; l < m; ++l) v1 = __builtin_fma(KtQuu[l], k[l], v1);
-#pragma unroll
-            for (int l = 0; l < m; ++l) v2 = __builtin_fma(Kc[l], Qu[l], v2);
-#pragma unroll
-            for (int l = 0; l < m; ++l) v3 = __builtin_fma(Qux[l], k[l], v3);
-            vx = ((Qx + v1) + v2) + v3;
-        }
-        double Vr[n];
-#pragma unroll
-        for (int j = 0; j < n; ++j) {
+            static_for<0, n>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                constexpr char kd = S::A_pat[r * n + j];
+                if constexpr (kd == 'x') fmac_row<r>(acc, Aw[j], Ri[r]);               // (A^T V_xx)[i][r] * A[r][j]
+                else if constexpr (kd == '1') acc = acc + Ri[r];
+            });
+            const double Qxx = sQk[cc * n + j] + acc;
             double t1 = 0.0, t2 = 0.0, t3 = 0.0;
 #pragma unroll
-            for (int l = 0; l < m; ++l) t1 = __builtin_fma(Qux[l], s[G::oK + l * n + j], t1);
+            for (int l = 0; l < m; ++l) fmac_row<j>(t1, Kc[l], Qux[l]);                // Q_ux[l][i] * K[l][j]
 #pragma unroll
-            for (int l = 0; l < m; ++l) t2 = __builtin_fma(Kc[l], s[G::oQux + l * n + j], t2);
+            for (int l = 0; l < m; ++l) fmac_row<j>(t2, Qux[l], Kc[l]);                // K[l][i] * Q_ux[l][j]
 #pragma unroll
-            for (int l = 0; l < m; ++l) t3 = __builtin_fma(KtQuu[l], s[G::oK + l * n + j], t3);
-            Vr[j] = ((Qxx[j] + t1) + t2) + t3;
-        }
-        // rows -> columns
-        if (row) {
-#pragma unroll
-            for (int j = 0; j < n; ++j) s[G::oT + c * LD + j] = Vr[j];
-        }
+            for (int l = 0; l < m; ++l) fmac_row<j>(t3, Kc[l], KtQuu[l]);              // (K^T Q_uu)[i][l] * K[l][j]
+            const double Vij = ((Qxx + t1) + t2) + t3;
+            if (row) s[G::oT + c * LD + j] = Vij;                                      // rows -> columns, part 1
+        });
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < n; ++r) Vc[r] = s[G::oT + r * LD + cc];
         __syncthreads();
+    };
+    double A0[n], B0[m], u0[m], A1[n], B1[m], u1[m];
+    load_rows(a.N - 1, A0, B0, u0);
+    for (int t = a.N - 1; t >= 0; t -= 2) {                                            // :82
+        step(t, A0, B0, u0, A1, B1, u1);
+        if (t > 0) step(t - 1, A1, B1, u1, A0, B0, u0);
     }
     if (act && c == 0) backward_epilogue(a, tile, pl, b, ecr, ecr_g, ecr_h, ok);
 }
