@@ -77,6 +77,7 @@ class _Emitter:
         self.trig = {}       # C text of a sin/cos argument -> index of its (sn_i, cs_i) pair
         self.trig_defs = []  # ordered definitions
         self.trig_args = []  # sin/cos arguments in order of first use
+        self.tan_defs = []   # (index, argument) of tan calls
         self.rcp = {}        # C text of a divisor -> index of its hoisted reciprocal
         self.rcp_defs = []
 
@@ -125,7 +126,7 @@ class _Emitter:
                 if key not in self.trig:
                     i = len(self.trig)
                     self.trig[key] = i
-                    self.trig_defs.append('const double tn%d = ILQR_DYN_TAN(%s);' % (i, arg))
+                    self.tan_defs.append((i, arg))
                 return 'tn%d' % self.trig[key]
             return '%s(%s)' % (_FUNCS[fname], arg)
         raise NotImplementedError(ast.dump(e))
@@ -200,6 +201,14 @@ def _function(model, what, mat):
         for a, i in em.trig_args:
             lines.append('        ILQR_DYN_SINCOS_SLOW(%s, sn%d, cs%d);' % (a, i, i))
         lines.append('    }')
+    # tan: in f, an argument whose sin/cos pair exists anyway becomes one quotient (ILQR_DYN_TAN_SC; dt-scaled like the
+    # sum formula above); elsewhere the library tan
+    pair = dict(em.trig_args)
+    for i, arg in em.tan_defs:
+        if what == 'f' and arg in pair:
+            lines.append('    const double tn%d = ILQR_DYN_TAN_SC(%s, sn%d, cs%d);' % (i, arg, pair[arg], pair[arg]))
+        else:
+            lines.append('    const double tn%d = ILQR_DYN_TAN(%s);' % (i, arg))
     for d in em.rcp_defs:
         lines.append('    ' + d)
     k = 0
@@ -222,7 +231,7 @@ def generate(name):
                  ' * Reference: /root/reference/python/symbolic_dynamics.py:23-25,88-90 (lambdify call sites).\n'
                  ' * Row-major: f out[n], A out[n*n] (A[i][j] = out[i*n+j]), B out[n*m].\n'
                  ' * The includer defines ILQR_DYN_FN, ILQR_DYN_CONST, ILQR_DYN_SINCOS(x, s, c), ILQR_DYN_SINCOS_SLOW(x, s, c),\n'
-                 ' * ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c), ILQR_DYN_TRIG_BIG(x), ILQR_DYN_TAN(x), ILQR_DYN_RCP(d), ILQR_DYN_DIV(a, d, rd) and must compile\n'
+                 ' * ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c), ILQR_DYN_TRIG_BIG(x), ILQR_DYN_TAN(x), ILQR_DYN_TAN_SC(x, s, c), ILQR_DYN_RCP(d), ILQR_DYN_DIV(a, d, rd) and must compile\n'
                  ' * with -ffp-contract=off. */'
                  % (name, name))
     parts.append('#ifndef ILQR_DYN_%s_H\n#define ILQR_DYN_%s_H' % (up, up))
