@@ -631,6 +631,101 @@ __device__ __forceinline__ double closed_loop(const KArgs& a, const double* Xp, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Line-search rollout for systems whose per-step record (x_ref, u_ref, K, k: n + 2m + mn doubles, 68 for the
+// quadcopter) is too large to prefetch in every lane's registers.  The W lanes of a problem need the SAME record, so the
+// wave loads each record once -- lane l fetches component l/G (+W, +2W, ...) of problem l%G, 64-byte runs of a tile row
+// -- and passes it through LDS (double buffered, one step ahead); every lane then reads its problem's record as
+// broadcasts.  10 vector loads per step and lane instead of 68 (W = 8), all in flight during the previous step.
+// Wave-synchronous: only this wave touches its LDS region and its LDS operations execute in order.
+// ------------------------------------------------------------------------------------------------
+template <class S, int W>
+struct Staged {
+    static constexpr int n = S::n, m = S::m, G = TILE / W;
+    static constexpr int REC = n + 2 * m + m * n, RECP = REC | 1;        // odd stride: the G records start in distinct banks
+    static constexpr int oX = 0, oU = n, oK = n + m, ok = n + m + m * n;
+    static constexpr int qX = (n + W - 1) / W, qU = (m + W - 1) / W, qK = (m * n + W - 1) / W;
+    static constexpr int WAVE_DOUBLES = 2 * G * RECP;
+    static constexpr bool use = (n + 2 * m + m * n) > 16 && W >= 8;      // smaller records are prefetched in registers
+};
+
+template <class S, int W, bool CKPT>
+__device__ __forceinline__ double closed_loop_staged(const KArgs& a, double* sw, const int lane, const int grp,
+                                                     const long long b_duty, double* ckp, const bool valid,
+                                                     double (&x)[S::n], const double (&p)[S::np],
+                                                     const double (&Rk)[S::m * S::m], const double alpha)
+{
+    using T = Staged<S, W>;
+    constexpr int n = S::n, m = S::m, G = T::G, RECP = T::RECP;
+    const int gd = lane % G, cd = lane / G;                                            // load duty: problem gd, component cd (+ W q)
+    const long long tile_d = b_duty >> 6;
+    const int pl_d = (int)(b_duty & 63);
+    const double* Xd = a.X + (size_t)tile_d * a.state_rows * n * TILE + pl_d;
+    const double* Ud = a.U + (size_t)tile_d * a.N * m * TILE + pl_d;
+    const double* Kd = a.KFB + (size_t)tile_d * a.N * (m * n) * TILE + pl_d;
+    const double* kd = a.KFF + (size_t)tile_d * a.N * m * TILE + pl_d;
+    double rX[T::qX], rU[T::qU], rK[T::qK], rk[T::qU];
+    auto fetch = [&](const int t) {
+#pragma unroll
+        for (int q = 0; q < T::qX; ++q) { const int c = cd + W * q; rX[q] = Xd[((size_t)t * n + (c < n ? c : n - 1)) * TILE]; }
+#pragma unroll
+        for (int q = 0; q < T::qU; ++q) { const int c = cd + W * q; rU[q] = Ud[((size_t)t * m + (c < m ? c : m - 1)) * TILE]; }
+#pragma unroll
+        for (int q = 0; q < T::qK; ++q) { const int c = cd + W * q; rK[q] = Kd[((size_t)t * (m * n) + (c < m * n ? c : m * n - 1)) * TILE]; }
+#pragma unroll
+        for (int q = 0; q < T::qU; ++q) { const int c = cd + W * q; rk[q] = kd[((size_t)t * m + (c < m ? c : m - 1)) * TILE]; }
+    };
+    auto stash = [&](const int t) {
+        double* d = sw + (t & 1) * (G * RECP) + gd * RECP;
+#pragma unroll
+        for (int q = 0; q < T::qX; ++q) { const int c = cd + W * q; if (c < n) d[T::oX + c] = rX[q]; }
+#pragma unroll
+        for (int q = 0; q < T::qU; ++q) { const int c = cd + W * q; if (c < m) d[T::oU + c] = rU[q]; }
+#pragma unroll
+        for (int q = 0; q < T::qK; ++q) { const int c = cd + W * q; if (c < m * n) d[T::oK + c] = rK[q]; }
+#pragma unroll
+        for (int q = 0; q < T::qU; ++q) { const int c = cd + W * q; if (c < m) d[T::ok + c] = rk[q]; }
+    };
+    fetch(0);
+    stash(0);
+    __builtin_amdgcn_wave_barrier();
+    double cost = 0.0;
+    int next_ck = CKPT ? a.ck : 0;
+    for (int t = 0; t < a.N; ++t) {
+        fetch(t + 1 < a.N ? t + 1 : t);                                                // next record, in flight during this step
+        const double* rec = sw + (t & 1) * (G * RECP) + grp * RECP;
+        if constexpr (CKPT) {
+            if (t == next_ck) {                                                        // state entering segment t / ck
+                if (valid) {
+                    double* c = ckp + (size_t)(t / a.ck) * n * TILE;
+#pragma unroll
+                    for (int i = 0; i < n; ++i) c[(size_t)i * TILE] = x[i];
+                }
+                next_ck += a.ck;
+            }
+        }
+        double u[m], xn[n], dx[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) dx[i] = x[i] - rec[T::oX + i];
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+            const double ff = alpha * rec[T::ok + j];                                  // :146
+            double fb = 0.0;                                                           // :147
+#pragma unroll
+            for (int i = 0; i < n; ++i) fb = __builtin_fma(rec[T::oK + j * n + i], dx[i], fb);
+            u[j] = (rec[T::oU + j] + fb) + ff;                                         // :148
+        }
+        cost = cost + input_cost<m>(u, Rk);
+        S::f(x, u, a.dt, p, xn);                                                       // :151
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = xn[i];
+        __builtin_amdgcn_wave_barrier();                                               // reads of this parity's other buffer are done
+        stash(t + 1);
+        __builtin_amdgcn_wave_barrier();
+    }
+    return cost;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_linesearch: ilqr.py:180-202.  W adjacent lanes evaluate W consecutive trials alpha_j of one problem
 // (64/W problems per wave); the accepted trial is the FIRST j whose Armijo ratio passes (:193), found with a
 // ballot over the lane group -- not the lowest cost.  Rounds of W trials repeat until accepted or exhausted.
@@ -687,7 +782,23 @@ __global__ void __launch_bounds__(W == 64 ? 512 : 256, ls_waves_per_simd<S>()) k
     const bool valid = act && j < a.n_trials;
     double c = __builtin_nan("");
     bool okj = false;
-    if (valid) {
+    if constexpr (Staged<S, W>::use) {
+        // whole wave together (the record loads are shared); lanes without a trial compute on and are ignored
+        __shared__ double sh[(W == 64 ? 8 : 4) * Staged<S, W>::WAVE_DOUBLES];
+        double* sw = sh + (threadIdx.x >> 6) * Staged<S, W>::WAVE_DOUBLES;
+        const long long b_duty = __shfl(b, (lane % G) * W);
+        const double alpha = a.alphas[j < a.n_trials ? j : 0];
+        double x[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = x0[i];
+        double* ckp = CKPT ? a.CKPT + (size_t)b * a.n_seg * n * TILE + j : nullptr;
+        c = closed_loop_staged<S, W, CKPT>(a, sw, lane, grp, b_duty, ckp, valid, x, p, Rk, alpha);
+        c = c + terminal_cost<n>(x, target, QT);
+        const double cost_difference = cur_cost - c;                               // :191
+        const double expected = alpha * dg + (alpha * alpha) * dh;                 // :192
+        okj = valid && (cost_difference / expected) > a.armijo_thr;                // :193 (NaN -> false)
+        if (!valid) c = __builtin_nan("");
+    } else if (valid) {
         const double alpha = a.alphas[j];
         double x[n];
 #pragma unroll

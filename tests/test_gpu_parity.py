@@ -220,13 +220,15 @@ def test_solve_vs_oracle_ragged_batch(amd, oracle, system, B, N):
         check_solve((states[b], inputs[b], k[b], K[b], cost[b]), ref[b])
 
 
-def test_alpha_width_does_not_change_results(amd):
-    """the number of concurrently evaluated line-search trials is a scheduling choice: same accepted trial, same bits"""
-    g, init, guess = random_batch('acrobot', 9, 150, seed=3)
-    f, A, Bf = dyn(amd, 'acrobot')
+@pytest.mark.parametrize('system,B,N,widths', [('acrobot', 9, 150, (1, 8, 64)), ('quadcopter', 11, 60, (1, 4, 8, 16, 32, 64))])
+def test_alpha_width_does_not_change_results(amd, system, B, N, widths):
+    """the number of concurrently evaluated line-search trials is a scheduling choice: same accepted trial, same bits.
+    For the quadcopter W >= 8 takes the LDS-staged rollout (one shared record per problem), W < 8 the per-lane loads."""
+    g, init, guess = random_batch(system, B, N, seed=3)
+    f, A, Bf = dyn(amd, system)
     outs = []
-    for W in (1, 8, 64):
-        s = amd.ilqr(init, g['target'], guess, float(g['dt']), 0.0, 150 * float(g['dt']) - 1e-9, f, A, Bf, g['Qk'], g['Rk'],
+    for W in widths:
+        s = amd.ilqr(init, g['target'], guess, float(g['dt']), 0.0, N * float(g['dt']) - 1e-9, f, A, Bf, g['Qk'], g['Rk'],
                      g['QT'], g['params'], 4, n_alpha_parallel=W)
         outs.append(s.solve() + (s.trace_.copy(),))
     for o in outs[1:]:
@@ -249,8 +251,9 @@ def test_fused_and_split_pipelines_agree_bitwise(amd, system):
 
 @pytest.mark.parametrize('system', ['pendulum', 'acrobot', 'cartpole'])
 def test_group_riccati_matches_lane_riccati(amd, system):
-    """the lane-group backward recursion (LDS hand-offs; the quadcopter's default) against the one-lane-per-problem
-    recursion on the systems where both exist: same operation order, so the same numbers to rounding"""
+    """the lane-group backward recursion (a row of 16 lanes per problem, DPALU row broadcasts; the quadcopter's default)
+    against the one-lane-per-problem recursion on the systems where both exist: same operation order, so the same
+    numbers to rounding"""
     from ilqr_amd import _lib
     g, init, guess = random_batch(system, 70, 130, seed=4)
     outs = []
