@@ -175,14 +175,17 @@ def main():
                                  ('linesearch', tot['rounds'] * N * work['fwd_round_bytes'], tot['trials'] * N * work['fwd_flops']),
                                  ('accept', tot['accepts'] * N * work['accept_bytes'], tot['accepts'] * N * work['fwd_flops']),
                                  ('linearize', 0, 0), ('rollout', 0, 0)):
-        ms, cnt = prof[name]
-        if cnt == 0:
+        ms, passes = prof[name]
+        if passes == 0:
             continue
+        # one HIP-event pair brackets a pass; a line-search pass is ceil(n_trials / W) launches of k_linesearch (one
+        # per round of W trials, later rounds on the compacted list) -- count launches the way rocprofv3 does
+        cnt = passes * (-(-info['n_trials'] // W) if name == 'linesearch' else 1)
         per_launch_ms = ms / max(cnt, 1)
         launches_per_step = cnt / max(args.steps, 1)
         b_launch = bytes_ / max(launches_per_step, 1)
         f_launch = flops_ / max(launches_per_step, 1)
-        kern[name] = dict(ms_per_launch=per_launch_ms, launches=cnt, ms_total=ms,
+        kern[name] = dict(ms_per_launch=per_launch_ms, launches=cnt, passes=passes, ms_per_pass=ms / passes, ms_total=ms,
                           gbs=b_launch / per_launch_ms / 1e6 if per_launch_ms > 0 else 0.0,
                           tflops=f_launch / per_launch_ms / 1e9 if per_launch_ms > 0 else 0.0,
                           bytes_per_launch=b_launch, flops_per_launch=f_launch)
@@ -215,7 +218,7 @@ def main():
 
     total_solves = B * world * args.steps
     value = total_solves / elapsed
-    pass_ms = sum(kern[k_]['ms_per_launch'] for k_ in ('backward', 'linesearch', 'accept', 'linearize') if k_ in kern)
+    pass_ms = sum(kern[k_]['ms_per_pass'] for k_ in ('backward', 'linesearch', 'accept', 'linearize') if k_ in kern)
     out = {
         'metric': 'iLQR solves/sec (fixed iters, batched)', 'value': round(value, 2), 'unit': 'solves/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),

@@ -14,5 +14,5 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ
   timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$n -- python3 $R/tools/pmc_probe.py > $OUT/pmc_$n.log 2>&1
 done
 cd $R && timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
-python3 tools/summarize_pmc.py $OUT > $OUT/pmc_summary.json
+python3 tools/summarize_pmc.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_summary.json
 echo done

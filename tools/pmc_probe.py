@@ -13,6 +13,9 @@ ws.set_weights(cfg['Qk'], cfg['Rk'], cfg['QT'])
 for f, a in ((_lib.F_INIT, cfg['init']), (_lib.F_TARGET, cfg['target']), (_lib.F_PARAMS, cfg['params']), (_lib.F_GUESS, cfg['guess'])):
     ws.upload(f, a)
 ws.solve(); ws.sync()
+import json
+info = ws.info()
+print('CONFIG ' + json.dumps(dict(system='acrobot', batch=B, n_timesteps=cfg['N'], n_alpha_parallel=info['n_alpha_parallel'], pipeline=info['pipeline'])))
 ws.cost(); ws.sync()
 tr = ws.download(_lib.F_TRACE)
 print('rounds', int(ws.download(_lib.F_LS_ROUNDS).sum()), 'accepts', int(ws.download(_lib.F_ACCEPTS).sum()), 'bwd', int(ws.download(_lib.F_ITERS).sum()))

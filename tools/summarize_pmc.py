@@ -39,6 +39,19 @@ def main():
             v['valu_busy_frac_of_simd_cycles'] = v['SQ_ACTIVE_INST_VALU'] * 4 / (v['GRBM_GUI_ACTIVE'] / 8 * 1024)
             v['valu_insts_per_launch'] = v.get('SQ_INSTS_VALU')
     print(json.dumps(out, indent=1, sort_keys=True))
+    if len(sys.argv) > 2:                       # second argument: write the per-kernel HBM traffic file bench.py reads
+        cfg = None
+        for f in glob.glob(os.path.join(d, 'pmc_*.log')):
+            for line in open(f, errors='replace'):
+                if line.startswith('CONFIG '):
+                    cfg = json.loads(line[7:])
+        tr = {'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_probe.py (tools/collect_profiles.sh); '
+                        'bytes per kernel launch, FETCH_SIZE x2 (gfx950), a line-search pass is one launch per round',
+              'config': cfg,
+              'kernels': {k: {'hbm_bytes_per_launch': v['hbm_bytes_per_launch'], 'read': v['hbm_read_bytes_per_launch'],
+                              'write': v['hbm_write_bytes_per_launch'], 'launches': v['launches']}
+                          for k, v in out.items() if 'hbm_bytes_per_launch' in v}}
+        json.dump(tr, open(sys.argv[2], 'w'), indent=1, sort_keys=True)
 
 if __name__ == '__main__':
     main()
