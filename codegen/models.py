@@ -1,4 +1,4 @@
-"""Symbolic models for the four systems of the hot path (own sympy code).
+"""Symbolic models for the systems of the hot path (own sympy code).
 
 Each builder returns a ``Model`` whose ``f_disc``/``A_disc``/``B_disc`` are the
 forward-Euler discretised dynamics and their Jacobians, exactly the triple the
@@ -13,6 +13,8 @@ reference lambdifies:
   same 15-digit literals when printed)
 * cartpole   -- spec: matlab/smooth-ilqr/symbolic_dynamics_cartpole.m:2-22
 * quadcopter -- spec: matlab/smooth-ilqr/symbolic_dynamics_quadcopter.m:3-51
+* car, double_integrator, double_pendulum -- specs: matlab/smooth-ilqr/symbolic_dynamics_{car,double_integrator,
+  double_pendulum}.m
 
 The MATLAB files are specifications only (read as text; nothing here executes
 them).  This module needs sympy and is used by ``codegen/gen_dynamics.py`` and
@@ -147,6 +149,57 @@ def quadcopter():
     return _finish('quadcopter', states, inputs, dt, Matrix([J_x, J_y, J_z, m, g, ell, k_1, k_2]), f)
 
 
-BUILDERS = {'pendulum': pendulum, 'acrobot': acrobot, 'cartpole': cartpole, 'quadcopter': quadcopter}
+def car():
+    """spec: matlab/smooth-ilqr/symbolic_dynamics_car.m:2-20 (unicycle: position, speed, heading; no physical parameters).
+    The MATLAB model has an EMPTY parameter vector; the compiled systems keep one unused slot (`unused`) so that every
+    array has a size -- the python drop-in pads an empty `parameters` argument."""
+    px, py, v, theta, v_dot, theta_dot, dt, unused = sp.symbols('px py v theta v_dot theta_dot dt unused')
+    states = Matrix([px, py, v, theta])
+    inputs = Matrix([v_dot, theta_dot])
+    f = Matrix([v * sp.cos(theta), v * sp.sin(theta), v_dot, theta_dot])
+    return _finish('car', states, inputs, dt, Matrix([unused]), f)
+
+
+def double_integrator():
+    """spec: matlab/smooth-ilqr/symbolic_dynamics_double_integrator.m:3-19"""
+    x, x_dot, force, m, dt = sp.symbols('x x_dot force m dt', real=True)
+    states = Matrix([x, x_dot])
+    inputs = Matrix([force])
+    f = Matrix([x_dot, force / m])
+    return _finish('double_integrator', states, inputs, dt, Matrix([m]), f)
+
+
+def double_pendulum():
+    """spec: matlab/smooth-ilqr/symbolic_dynamics_double_pendulum.m:3-58 -- the acrobot's two links with BOTH joints
+    actuated (tau = [tau_1; tau_2]); built with the same sequence as acrobot() above."""
+    q1, q2, q1_dot, q2_dot = sp.symbols('q1 q2 q1_dot q2_dot')
+    tau_1, tau_2 = sp.symbols('tau_1 tau_2')
+    m1, L1, m2, L2, g, dt = sp.symbols('m1 L1 m2 L2 g dt ')
+    q = Matrix([[q1], [q2]])
+    q_dot = Matrix([[q1_dot], [q2_dot]])
+    tau = Matrix([[tau_1], [tau_2]])
+    states = Matrix([[q], [q_dot]])
+    inputs = Matrix([tau_1, tau_2])
+    M1 = Matrix([[m1, 0, 0], [0, m1, 0], [0, 0, 1 / 12 * m1 * L1 * L1]])
+    M2 = Matrix([[m2, 0, 0], [0, m2, 0], [0, 0, 1 / 12 * m2 * L2 * L2]])
+    Jb_sL1 = Matrix([[0, 0], [L1 / 2, 0], [1, 0]])
+    Jb_sL2 = Matrix([[L1 * sp.sin(q2), 0], [L1 * sp.cos(q2) + L2 / 2, L2 / 2], [1, 1]])
+    M = sp.simplify(Jb_sL1.T @ M1 @ Jb_sL1 + Jb_sL2.T @ M2 @ Jb_sL2)
+    nq = 2
+    C = sp.zeros(nq, nq)
+    for ii in range(nq):
+        for jj in range(nq):
+            for kk in range(nq):
+                C[ii, jj] = C[ii, jj] + 1 / 2 * (sp.diff(M[ii, jj], q[kk]) + sp.diff(M[ii, kk], q[jj])
+                                                 - sp.diff(M[jj, kk], q[ii])) * q_dot[kk]
+    V = Matrix([(m1 * g * L1 / 2 * sp.sin(q1) + m2 * g * (L1 * sp.sin(q1) + L2 / 2 * sp.sin(q1 + q2)))])
+    N = V.jacobian(q).T
+    f = Matrix([q_dot, M.inv() @ (tau - N - C @ q_dot)])
+    return _finish('double_pendulum', states, inputs, dt, Matrix([m1, L1, m2, L2, g]), f)
+
+
+BUILDERS = {'pendulum': pendulum, 'acrobot': acrobot, 'cartpole': cartpole, 'quadcopter': quadcopter, 'car': car,
+            'double_integrator': double_integrator, 'double_pendulum': double_pendulum}
 # system ids are part of the C-ABI (include/ilqr_hip.h)
-SYSTEM_IDS = {'pendulum': 0, 'acrobot': 1, 'cartpole': 2, 'quadcopter': 3}
+SYSTEM_IDS = {'pendulum': 0, 'acrobot': 1, 'cartpole': 2, 'quadcopter': 3, 'car': 4, 'double_integrator': 5,
+              'double_pendulum': 6}

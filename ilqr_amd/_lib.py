@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ILQR_HIP_LIB: alternative build of the same library (A/B timing of kernel variants); never a different backend
 LIB_PATH = os.environ.get('ILQR_HIP_LIB') or os.path.join(_HERE, 'libilqr_hip.so')
 
-SYSTEM_IDS = {'pendulum': 0, 'acrobot': 1, 'cartpole': 2, 'quadcopter': 3}
+SYSTEM_IDS = {'pendulum': 0, 'acrobot': 1, 'cartpole': 2, 'quadcopter': 3, 'car': 4, 'double_integrator': 5,
+              'double_pendulum': 6}
 STATUS_NAMES = {0: 'max_iter', 1: 'optimal', 2: 'low_learning_rate', 3: 'numerical'}
 
 # fields of the device-resident workspace (include/ilqr_hip.h)
@@ -108,6 +109,17 @@ def require_gpu():
 
 def f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+NO_PARAMETER_SYSTEMS = ('car',)     # MATLAB models with `parameters = []`: compiled with one unused slot
+
+
+def params_of(system, parameters):
+    """float64 parameters; an empty vector for a system without physical parameters fills its unused slot."""
+    p = f64(parameters)
+    if p.size == 0 and system in NO_PARAMETER_SYSTEMS:
+        p = np.zeros(1)
+    return p
 
 
 def dptr(a):

@@ -44,6 +44,9 @@
 #include "dynamics/acrobot.h"
 #include "dynamics/cartpole.h"
 #include "dynamics/quadcopter.h"
+#include "dynamics/car.h"
+#include "dynamics/double_integrator.h"
+#include "dynamics/double_pendulum.h"
 
 namespace {
 
@@ -73,9 +76,14 @@ ILQR_DEFINE_SYSTEM(pendulum, PENDULUM)
 ILQR_DEFINE_SYSTEM(acrobot, ACROBOT)
 ILQR_DEFINE_SYSTEM(cartpole, CARTPOLE)
 ILQR_DEFINE_SYSTEM(quadcopter, QUADCOPTER)
+ILQR_DEFINE_SYSTEM(car, CAR)
+ILQR_DEFINE_SYSTEM(double_integrator, DOUBLE_INTEGRATOR)
+ILQR_DEFINE_SYSTEM(double_pendulum, DOUBLE_PENDULUM)
 
 struct SysInfo { const char* name; int n, m, np; };
-const SysInfo SYSTEMS[4] = {{"pendulum", 2, 1, 3}, {"acrobot", 4, 1, 5}, {"cartpole", 4, 1, 4}, {"quadcopter", 12, 4, 8}};
+constexpr int N_SYSTEMS = 7;
+const SysInfo SYSTEMS[N_SYSTEMS] = {{"pendulum", 2, 1, 3}, {"acrobot", 4, 1, 5}, {"cartpole", 4, 1, 4}, {"quadcopter", 12, 4, 8},
+                                    {"car", 4, 2, 1}, {"double_integrator", 2, 1, 1}, {"double_pendulum", 4, 2, 5}};
 
 // ------------------------------------------------------------------------------------------------
 // kernel arguments
@@ -1416,17 +1424,34 @@ __global__ void __launch_bounds__(64) k_ltvlqr(const KArgs a)
     const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
     double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + lane;
     bool ok = true;
-    double x[n], u[m];
-    load_col<n>(Xp + (size_t)(a.N - 1) * n * TILE, x);
-    load_col<m>(Up + (size_t)(a.N - 1) * m * TILE, u);
-    for (int t = a.N - 1; t >= 0; --t) {                                               // :15
-        double xnext[n], unext[m];
-        const int tp = t > 0 ? t - 1 : 0;
-        load_col<n>(Xp + (size_t)tp * n * TILE, xnext);
-        load_col<m>(Up + (size_t)tp * m * TILE, unext);
+    // ring of D trajectory rows in flight (as in k_riccati): at 65 536 problems every SIMD holds one wave, and one step
+    // of dependent arithmetic is shorter than an HBM round trip
+    constexpr int D = (n + m) <= 8 ? RICCATI_PREFETCH : 1;
+    double xr[D][n], ur[D][m];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int tl = a.N - 1 - d > 0 ? a.N - 1 - d : 0;
+        load_col<n>(Xp + (size_t)tl * n * TILE, xr[d]);
+        load_col<m>(Up + (size_t)tl * m * TILE, ur[d]);
+    }
+    for (int t0 = a.N - 1; t0 >= 0; t0 -= D) {                                         // :15
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int t = t0 - d;
+        if (t < 0) break;
+        double x[n], u[m];
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = xr[d][i];
+#pragma unroll
+        for (int j = 0; j < m; ++j) u[j] = ur[d][j];
         double A[n * n], Bm[n * m];
         S::A(x, u, a.dt, p, A);                                                        // :21
         S::B(x, u, a.dt, p, Bm);                                                       // :22
+        {
+            const int tl = t - D > 0 ? t - D : 0;                                      // slot d next holds step t - D
+            load_col<n>(Xp + (size_t)tl * n * TILE, xr[d]);
+            load_col<m>(Up + (size_t)tl * m * TILE, ur[d]);
+        }
         double BtP[m * n], BtPA[m * n], G[m * m], Gi[m * m], K[m * n];
 #pragma unroll
         for (int j = 0; j < m; ++j)
@@ -1505,10 +1530,7 @@ __global__ void __launch_bounds__(64) k_ltvlqr(const KArgs a)
         }
 #pragma unroll
         for (int i = 0; i < n * n; ++i) P[i] = Pn[i];
-#pragma unroll
-        for (int i = 0; i < n; ++i) x[i] = xnext[i];
-#pragma unroll
-        for (int j = 0; j < m; ++j) u[j] = unext[j];
+      }
     }
     if (!ok) a.status[tile * TILE + lane] = ILQR_STATUS_NUMERICAL;
 }
@@ -1666,6 +1688,9 @@ int with_system(int sys, F&& fn)
         case 1: return fn(Sys_acrobot{});
         case 2: return fn(Sys_cartpole{});
         case 3: return fn(Sys_quadcopter{});
+        case 4: return fn(Sys_car{});
+        case 5: return fn(Sys_double_integrator{});
+        case 6: return fn(Sys_double_pendulum{});
     }
     return fail(-2, "unknown system id %d", sys);
 }
@@ -1969,7 +1994,7 @@ int ws_solve_chain(ilqr_ws* ws, int sub)
 int validate_desc(const ilqr_desc* d)
 {
     if (!d) return fail(-1, "null descriptor");
-    if (d->system_id < 0 || d->system_id > 3) return fail(-2, "unknown system id %d", d->system_id);
+    if (d->system_id < 0 || d->system_id >= N_SYSTEMS) return fail(-2, "unknown system id %d", d->system_id);
     if (d->batch < 1) return fail(-1, "batch must be >= 1 (got %lld)", (long long)d->batch);
     if (d->n_timesteps < 1) return fail(-1, "n_timesteps must be >= 1 (got %d)", d->n_timesteps);
     if (d->n_iterations < 0) return fail(-1, "n_iterations must be >= 0");
@@ -2019,7 +2044,7 @@ const char* ilqr_last_error(void) { return g_err; }
 
 int ilqr_system_dims(int32_t sys, int32_t* n, int32_t* m, int32_t* np)
 {
-    if (sys < 0 || sys > 3) return fail(-2, "unknown system id %d", sys);
+    if (sys < 0 || sys >= N_SYSTEMS) return fail(-2, "unknown system id %d", sys);
     if (n) *n = SYSTEMS[sys].n;
     if (m) *m = SYSTEMS[sys].m;
     if (np) *np = SYSTEMS[sys].np;
@@ -2029,18 +2054,18 @@ int ilqr_system_dims(int32_t sys, int32_t* n, int32_t* m, int32_t* np)
 int ilqr_system_lookup(const char* name, int32_t* n, int32_t* m, int32_t* np)
 {
     if (!name) return fail(-2, "null system name");
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < N_SYSTEMS; ++i)
         if (strcmp(name, SYSTEMS[i].name) == 0) {
             ilqr_system_dims(i, n, m, np);
             return i;
         }
-    return fail(-2, "unknown system '%s' (compiled in: pendulum, acrobot, cartpole, quadcopter)", name);
+    return fail(-2, "unknown system '%s' (compiled in: pendulum, acrobot, cartpole, quadcopter, car, double_integrator, double_pendulum)", name);
 }
 
 int ilqr_dynamics_eval(int32_t sys, int32_t which, int64_t count, const double* x, const double* u, double dt,
                        const double* params, double* out, int32_t device)
 {
-    if (sys < 0 || sys > 3) return fail(-2, "unknown system id %d", sys);
+    if (sys < 0 || sys >= N_SYSTEMS) return fail(-2, "unknown system id %d", sys);
     if (which < 0 || which > 2) return fail(-1, "which must be 0 (f), 1 (A) or 2 (B)");
     if (count < 0) return fail(-1, "negative count");
     if (count == 0) return 0;

@@ -58,7 +58,7 @@ class ilqr:
         if np.shape(initial_guess)[-2] != self.n_timesteps_:
             raise ValueError('initial_guess has %d rows but np.arange(start_time, end_time, dt) has %d steps'
                              % (np.shape(initial_guess)[-2], self.n_timesteps_))
-        if np.size(parameters) % npar != 0:
+        if np.size(_lib.params_of(self.system_, parameters)) % npar != 0 or np.size(_lib.params_of(self.system_, parameters)) == 0:
             raise ValueError('%s takes %d parameters' % (self.system_, npar))
 
     # ------------------------------------------------------------------ helpers
@@ -79,7 +79,7 @@ class ilqr:
         return (t, True) if t.ndim == 2 else (t.reshape(-1), False)
 
     def _params(self):
-        p = _lib.f64(self.parameters_)
+        p = _lib.params_of(self.system_, self.parameters_)
         return (p, True) if p.ndim == 2 else (p.reshape(-1), False)
 
     def _desc(self, n_iterations=0):

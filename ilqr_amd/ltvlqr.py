@@ -24,7 +24,7 @@ def ltvlqr(states, inputs, A, B, Q_k, R_k, Q_T, dt, parameters, device=0):
     rows = states.shape[1]
     if states.shape[2] != n or inputs.shape[2] != m:
         raise ValueError('%s expects %d states and %d inputs' % (system, n, m))
-    params = _lib.f64(parameters)
+    params = _lib.params_of(system, parameters)
     pb = params.ndim == 2
     desc = _lib.make_desc(system, N, Bn, dt, device=device, params_batched=pb)
     K = np.empty((Bn, N, m, n))                                   # ltvlqr.py:12

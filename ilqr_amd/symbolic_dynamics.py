@@ -23,7 +23,7 @@ class CompiledDynamics:
     def __call__(self, states, inputs, dt, parameters, device=0):
         x = _lib.f64(states).reshape(-1)
         u = _lib.f64(inputs).reshape(-1)
-        p = _lib.f64(parameters).reshape(-1)
+        p = _lib.params_of(self.system, parameters).reshape(-1)
         if x.size != self.n or u.size != self.m or p.size != self.n_params:
             raise ValueError('%s %s expects %d states, %d inputs, %d parameters'
                              % (self.system, self.which, self.n, self.m, self.n_params))
@@ -35,7 +35,7 @@ class CompiledDynamics:
         _lib.require_gpu()
         x = _lib.f64(states).reshape(-1, self.n)
         u = _lib.f64(inputs).reshape(-1, self.m)
-        p = _lib.f64(parameters).reshape(-1)
+        p = _lib.params_of(self.system, parameters).reshape(-1)
         cnt = x.shape[0]
         shape = {'f': (cnt, self.n), 'A': (cnt, self.n, self.n), 'B': (cnt, self.n, self.m)}[self.which]
         out = np.empty(shape)
@@ -70,6 +70,23 @@ def symbolic_dynamics_cartpole():
 def symbolic_dynamics_quadcopter():
     """matlab/smooth-ilqr/symbolic_dynamics_quadcopter.m (12 states, 4 inputs; parameters [J_x J_y J_z m g ell k_1 k_2])."""
     return _triple('quadcopter')
+
+
+def symbolic_dynamics_car():
+    """matlab/smooth-ilqr/symbolic_dynamics_car.m (states [px, py, v, theta]; inputs [v_dot, theta_dot]; the MATLAB model has
+    no parameters: pass ``[]`` -- or anything of length <= 1 -- as ``parameters``)."""
+    return _triple('car')
+
+
+def symbolic_dynamics_double_integrator():
+    """matlab/smooth-ilqr/symbolic_dynamics_double_integrator.m (states [x, x_dot]; input force; parameters [m])."""
+    return _triple('double_integrator')
+
+
+def symbolic_dynamics_double_pendulum():
+    """matlab/smooth-ilqr/symbolic_dynamics_double_pendulum.m (the acrobot with both joints actuated; parameters
+    [m1, L1, m2, L2, g])."""
+    return _triple('double_pendulum')
 
 
 def system_of(*callables):

@@ -30,7 +30,7 @@ def tracking_rollout(states, inputs, K_feedback, f, init_state, dt, parameters, 
     _lib.require_gpu()
     init = _lib.f64(init_state)
     states, inputs, K = _lib.f64(states), _lib.f64(inputs), _lib.f64(K_feedback)
-    params = _lib.f64(parameters)
+    params = _lib.params_of(system, parameters)
     batched = init.ndim == 2 or inputs.ndim == 3 or K.ndim == 4
     Bn = max(init.shape[0] if init.ndim == 2 else 1, inputs.shape[0] if inputs.ndim == 3 else 1,
              K.shape[0] if K.ndim == 4 else 1, states.shape[0] if states.ndim == 3 else 1)

@@ -11,7 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, 'libilqr_oracle.so')
-SYSTEM_IDS = {'pendulum': 0, 'acrobot': 1, 'cartpole': 2, 'quadcopter': 3}
+SYSTEM_IDS = {'pendulum': 0, 'acrobot': 1, 'cartpole': 2, 'quadcopter': 3, 'car': 4, 'double_integrator': 5,
+              'double_pendulum': 6}
 DEFAULT_OPTS = (0.95, 0.05, 1e-3, 0.1)   # ilqr.py:166-169
 
 _lib = None

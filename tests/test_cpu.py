@@ -11,7 +11,8 @@ import pytest
 
 from conftest import ROOT, golden, rel_err
 
-SYSTEMS = ['pendulum', 'acrobot', 'cartpole', 'quadcopter']
+SYSTEMS = ['pendulum', 'acrobot', 'cartpole', 'quadcopter', 'car', 'double_integrator', 'double_pendulum']
+KAT_SYSTEMS = ['pendulum', 'acrobot', 'cartpole', 'quadcopter', 'car']     # systems with a MATLAB *-trajectory.mat
 TOL = 1e-8
 
 
@@ -26,7 +27,7 @@ def test_oracle_dynamics_match_lambdify(oracle, system):
         assert np.mean(out == d[which]) > 0.99
 
 
-@pytest.mark.parametrize('system', SYSTEMS)
+@pytest.mark.parametrize('system', KAT_SYSTEMS)
 def test_oracle_dynamics_matlab_kat(oracle, system):
     k = golden('mat_kat_' + system)
     out = oracle.dynamics(system, 'f', k['x'], k['u'], float(k['dt']), k['params'])
@@ -49,7 +50,7 @@ def test_oracle_single_passes(oracle, system):
         assert rel_err(np.vstack([fu[::stride], fu[-1:]]), p['fwd%d_inputs' % i]) < 1e-12
 
 
-@pytest.mark.parametrize('system', ['pendulum', 'acrobot', 'quadcopter'])
+@pytest.mark.parametrize('system', ['pendulum', 'acrobot', 'quadcopter', 'car', 'double_integrator'])
 def test_oracle_full_solve(oracle, system):
     g = golden(system + '_solve')
     r = oracle.solve(system, g['init'], g['target'], g['guess'], g['Qk'], g['Rk'], g['QT'], float(g['dt']), g['params'],
@@ -68,6 +69,18 @@ def test_oracle_cartpole_conditioning(oracle):
     r = oracle.solve('cartpole', g['init'], g['target'], g['guess'], g['Qk'], g['Rk'], g['QT'], float(g['dt']), g['params'], 15)
     assert np.array_equal(r['trace'][:15, 4], g['trace'][:15, 4])
     assert rel_err(r['trace'][:6, 0], g['trace'][:6, 0]) < TOL
+
+
+def test_oracle_double_pendulum_conditioning(oracle):
+    """the two-input swing-up (18 iterations) amplifies rounding like the cartpole: every Armijo decision agrees with the
+    reference, the iteration costs agree to 1e-8 over the first 8 iterations and the final trajectory to 1e-6"""
+    g = golden('double_pendulum_solve')
+    r = oracle.solve('double_pendulum', g['init'], g['target'], g['guess'], g['Qk'], g['Rk'], g['QT'], float(g['dt']),
+                     g['params'], int(g['n_iterations']))
+    assert r['iters'] == g['iters'] and r['status'] == g['status']
+    assert np.array_equal(r['trace'][:r['iters'], 4], g['trace'][:, 4])
+    assert rel_err(r['trace'][:8, 0], g['trace'][:8, 0]) < TOL
+    assert rel_err(r['states'], g['states']) < 1e-6 and rel_err(r['K'], g['K']) < 1e-6
 
 
 @pytest.mark.parametrize('system', SYSTEMS)

@@ -155,7 +155,32 @@ def cfg_quadcopter():  # example_quadcopter.m:4-34
                 QT=100 * np.eye(12), params=np.array([0.05, 0.05, 0.09, 0.8, 9.8, 0.33, 4, 0.05]), n_iterations=100)
 
 
-CONFIG = {'pendulum': cfg_pendulum, 'acrobot': cfg_acrobot, 'cartpole': cfg_cartpole, 'quadcopter': cfg_quadcopter}
+def cfg_car():   # example_car_accelerate.m:4-35 (time span end-exclusive as in the python reference; parameters = [])
+    dt, t0, t1 = 0.005, 0, 4
+    N = np.arange(t0, t1, dt).shape[0]
+    return dict(dt=dt, start=t0, end=t1, init=np.zeros(4), target=np.array([4.0, 0, 1.0, 0]), guess=np.zeros((N, 2)),
+                Qk=np.zeros((4, 4)), Rk=0.0001 * np.eye(2), QT=100 * np.eye(4), params=np.zeros(1), n_iterations=50)
+
+
+def cfg_double_integrator():   # example_double_integrator.m:5-33 (unconstrained: the python reference has no bounds)
+    dt, t0, t1 = 0.01, 0, 3
+    N = np.arange(t0, t1, dt).shape[0]
+    return dict(dt=dt, start=t0, end=t1, init=np.array([-2.0, 0]), target=np.zeros(2), guess=np.ones((N, 1)),
+                Qk=np.zeros((2, 2)), Rk=0.001 * np.eye(1), QT=100 * np.eye(2), params=np.array([1.0]), n_iterations=50)
+
+
+def cfg_double_pendulum():   # example_double_pendulum.m:4-38 (horizon shortened from 4 s to 2 s to keep the fixture small)
+    dt, t0, t1 = 0.001, 0, 2
+    N = np.arange(t0, t1, dt).shape[0]
+    rng = np.random.default_rng(1)
+    QT = 10 * np.eye(4); QT[0, 0] = 1000; QT[1, 1] = 1000
+    return dict(dt=dt, start=t0, end=t1, init=np.array([-np.pi / 2, 0, 0, 0]), target=np.array([np.pi / 2, 0, 0, 0]),
+                guess=0.1 * rng.standard_normal((N, 2)), Qk=np.zeros((4, 4)), Rk=0.001 * np.eye(2), QT=QT,
+                params=np.array([1, 1, 2, 1, 9.8]), n_iterations=50)
+
+
+CONFIG = {'pendulum': cfg_pendulum, 'acrobot': cfg_acrobot, 'cartpole': cfg_cartpole, 'quadcopter': cfg_quadcopter,
+          'car': cfg_car, 'double_integrator': cfg_double_integrator, 'double_pendulum': cfg_double_pendulum}
 
 
 def make(c, fab, cls=TracedIlqr, **over):
@@ -200,7 +225,8 @@ def gen_dynamics(name, fab):
 def gen_mat_kats():
     mdir = '/root/reference/matlab/smooth-ilqr'
     for name, fn in (('pendulum', 'swingup-trajectory.mat'), ('acrobot', 'acrobot-swingup-trajectory.mat'),
-                     ('cartpole', 'cartpole-swingup-trajectory.mat'), ('quadcopter', 'quadcopter-trajectory.mat')):
+                     ('cartpole', 'cartpole-swingup-trajectory.mat'), ('quadcopter', 'quadcopter-trajectory.mat'),
+                     ('car', 'car-accelerate-trajectory.mat')):
         d = scipy.io.loadmat(os.path.join(mdir, fn))
         states = np.asarray(d['states'], float)
         inputs = np.asarray(d['inputs'], float)
@@ -214,7 +240,7 @@ def gen_mat_kats():
         T = min(states.shape[0] - 1, inputs.shape[0])
         idx = np.unique(np.linspace(0, T - 1, 64).astype(int))
         save('mat_kat_' + name, x=states[idx], u=inputs[idx], x_next=states[idx + 1], dt=np.float64(d['dt'].item()),
-             params=np.asarray(d['parameters'], float).reshape(-1))
+             params=np.asarray(d['parameters'], float).reshape(-1) if np.size(d['parameters']) else np.zeros(1))
 
 
 def gen_passes(name, fab, alphas=(1.0, 0.95 ** 3, 0.95 ** 20)):
@@ -251,11 +277,13 @@ def gen_batch(name, fab, B=8):
     c = CONFIG[name]()
     n = len(c['init'])
     m = c['guess'].shape[1]
-    short = {'pendulum': 1.0, 'acrobot': 0.4, 'cartpole': 1.5, 'quadcopter': 0.5}[name]
+    short = {'pendulum': 1.0, 'acrobot': 0.4, 'cartpole': 1.5, 'quadcopter': 0.5, 'car': 1.0, 'double_integrator': 1.0,
+             'double_pendulum': 0.4}[name]
     rng = np.random.default_rng(7 + models.SYSTEM_IDS[name])
     N = np.arange(c['start'], short, c['dt']).shape[0]
     inits = np.asarray(c['init'], float) + rng.uniform(-0.2, 0.2, (B, n))
-    scale = {'pendulum': 0.1, 'acrobot': 0.5, 'cartpole': 0.05, 'quadcopter': 0.02}[name]
+    scale = {'pendulum': 0.1, 'acrobot': 0.5, 'cartpole': 0.05, 'quadcopter': 0.02, 'car': 0.2, 'double_integrator': 0.2,
+             'double_pendulum': 0.2}[name]
     guesses = c['guess'][:N][None] + scale * rng.standard_normal((B, N, m))
     res = []
     for b in range(B):
