@@ -9,13 +9,13 @@
  * checker / the CPU baseline only.  ilqr_amd/ (the product) never loads this library.
  *
  * Pinned against the reference itself: tools/make_golden.py imports the reference python in the
- * build container and commits its outputs under tests/golden/; tests/test_oracle_golden.py
+ * build container and commits its outputs under tests/golden/; tests/test_cpu.py
  * checks every function below against those fixtures (and against the reference's own committed
  * acrobot_swingup_{states,inputs}.csv rows kept in the fixtures).
  *
  * Dynamics: the generated headers ilqr_amd/csrc/dynamics/<system>.h (same expression tree and
- * literals as the reference's lambdified callables, symbolic_dynamics.py:23-25,88-90; cartpole and
- * quadcopter are re-derived from the MATLAB specs), compiled here by gcc against glibc libm.
+ * literals as the reference's lambdified callables, symbolic_dynamics.py:23-25,88-90; cartpole,
+ * quadcopter, car, double_integrator and double_pendulum are re-derived from the MATLAB specs), compiled here by gcc against glibc libm.
  *
  * Layout of every array: the reference's numpy layout, C-contiguous float64, with an optional
  * leading batch axis handled by the *_batched entry points (OpenMP over problems).
