@@ -1,0 +1,671 @@
+// kernels_backward.h -- backward side: k_backward, k_linearize, k_riccati, k_riccati_grp, k_ltvlqr (ilqr.py:64-135, ltvlqr.py:3-28)
+// Part of ilqr_hip.hip (included inside its anonymous namespace, in this order: kernels_common.h,
+// kernels_backward.h, kernels_forward.h, kernels_util.h); not a stand-alone header.
+template <class S>
+__device__ __forceinline__ void terminal_value(const double* xNp, const double (&target)[S::n],
+                                               const double (&Vxx)[S::n * S::n], double (&Vx)[S::n])
+{
+    constexpr int n = S::n;
+    double xN[n], ed[n];
+    load_col<n>(xNp, xN);
+#pragma unroll
+    for (int i = 0; i < n; ++i) ed[i] = xN[i] - target[i];                             // :68
+#pragma unroll
+    for (int i = 0; i < n; ++i) {                                                      // :70
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < n; ++c) s = __builtin_fma(Vxx[i * n + c], ed[c], s);
+        Vx[i] = s;
+    }
+}
+
+// end of backwards_pass for one active problem: expected reductions (:128-130), iteration count, the "optimal"
+// stop test of solve (:175), trace row
+__device__ __forceinline__ void backward_epilogue(const KArgs& a, long long tile, int lane, long long b, double ecr,
+                                                  double ecr_g, double ecr_h, bool ok)
+{
+    double* dj = a.dJ + (size_t)tile * 3 * TILE + lane;
+    dj[0] = ecr; dj[TILE] = ecr_g; dj[2 * TILE] = ecr_h;
+    a.iters[b] += 1;
+    int still = 1;
+    if (!ok) { a.status[b] = ILQR_STATUS_NUMERICAL; still = 0; }
+    else if (fabs(ecr) < a.low_red) { a.status[b] = ILQR_STATUS_OPTIMAL; still = 0; }
+    if (!still) a.active[b] = 0;
+    if (a.trace && a.it < a.n_iter) {
+        double* tr = a.trace + ((size_t)tile * a.n_iter + a.it) * 6 * TILE + lane;
+        tr[0 * TILE] = a.cost[b]; tr[1 * TILE] = ecr; tr[2 * TILE] = ecr_g; tr[3 * TILE] = ecr_h;
+        tr[4 * TILE] = -1.0; tr[5 * TILE] = __builtin_nan("");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_backward: ilqr.py:64-135.  One lane per problem; V_x, V_xx and the step's Q_* stay in VGPRs.
+// ------------------------------------------------------------------------------------------------
+template <class S>
+__global__ void __launch_bounds__(64) k_backward(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m, np = S::np;
+    const long long tile = a.tile0 + blockIdx.x;
+    const int lane = threadIdx.x;
+    const long long b = tile * TILE + lane;
+    const bool act = a.active[b] != 0;
+    if (__ballot(act) == 0ull) return;   // whole tile finished
+    double p[np], target[n], Qk[n * n], Rk[m * m], Vx[n], Vxx[n * n];
+    load_col<np>(a.PARAMS + (size_t)tile * np * TILE + lane, p);
+    load_col<n>(a.TARGET + (size_t)tile * n * TILE + lane, target);
+    load_uniform<n * n>(a.WTS, Qk);
+    load_uniform<m * m>(a.WTS + n * n, Rk);
+    load_uniform<n * n>(a.WTS + n * n + m * m, Vxx);                                   // :67  V_xx = Q_T
+    const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
+    const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+    double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + lane;
+    double* kp = a.KFF + (size_t)tile * a.N * m * TILE + lane;
+    terminal_value<S>(Xp + (size_t)a.N * n * TILE, target, Vxx, Vx);
+    double ecr = 0.0, ecr_g = 0.0, ecr_h = 0.0;
+    bool ok = true;
+    double x[n], u[m];
+    load_col<n>(Xp + (size_t)(a.N - 1) * n * TILE, x);
+    load_col<m>(Up + (size_t)(a.N - 1) * m * TILE, u);
+    for (int t = a.N - 1; t >= 0; --t) {                                               // :82
+        double xnext[n], unext[m];                                                     // prefetch step t-1
+        const int tp = t > 0 ? t - 1 : 0;
+        load_col<n>(Xp + (size_t)tp * n * TILE, xnext);
+        load_col<m>(Up + (size_t)tp * m * TILE, unext);
+        double A[n * n], Bm[n * m], k[m], K[m * n], g, h;
+        S::A(x, u, a.dt, p, A);                                                        // :96
+        S::B(x, u, a.dt, p, Bm);                                                       // :97
+        ok = Riccati<S>::step(A, Bm, u, Qk, Rk, a.quu_reg, Vx, Vxx, k, K, g, h) && ok;
+        if (act) {
+            store_col<m>(kp + (size_t)t * m * TILE, k);                                // :111
+            store_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K);                      // :112
+        }
+        const double cur = g + h;                                                      // :117
+        ecr_g += g; ecr_h += h; ecr += cur;                                            // :119-121
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = xnext[i];
+#pragma unroll
+        for (int j = 0; j < m; ++j) u[j] = unext[j];
+    }
+    if (act) backward_epilogue(a, tile, lane, b, ecr, ecr_g, ecr_h, ok);
+}
+
+template <class S>
+struct Lin {
+    static constexpr int count_x(const char* pat, int len)
+    {
+        int c = 0;
+        for (int i = 0; i < len; ++i) c += pat[i] == 'x';
+        return c;
+    }
+    static constexpr int nA = count_x(S::A_pat, S::n * S::n);
+    static constexpr int nB = count_x(S::B_pat, S::n * S::m);
+    static constexpr int n_lin = nA + nB;
+};
+
+constexpr int LIN_TS = 8;   // time steps per wave in k_linearize
+
+template <class S, bool COPY>
+__global__ void __launch_bounds__(64) k_linearize(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m, np = S::np;
+    const int chunks = (a.N + LIN_TS - 1) / LIN_TS;
+    const long long tile = a.tile0 + blockIdx.x / chunks;
+    const int chunk = (int)(blockIdx.x % chunks);
+    const int lane = threadIdx.x;
+    const long long b = tile * TILE + lane;
+    const bool act = a.active[b] != 0;
+    const bool run = COPY ? (act && a.acc_j[b] >= 0) : act;
+    if (__ballot(run) == 0ull) return;
+    if (!run) return;
+    double p[np];
+    load_col<np>(a.PARAMS + (size_t)tile * np * TILE + lane, p);
+    double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
+    double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+    const double* X2p = a.X2 + (size_t)tile * a.state_rows * n * TILE + lane;
+    const double* U2p = a.U2 + (size_t)tile * a.N * m * TILE + lane;
+    double* Lp = a.LIN + (size_t)tile * a.N * Lin<S>::n_lin * TILE + lane;
+    const int t0 = chunk * LIN_TS;
+    const int t1 = t0 + LIN_TS < a.N ? t0 + LIN_TS : a.N;
+    for (int t = t0; t < t1; ++t) {
+        double x[n], u[m];
+        if constexpr (COPY) {
+            if (t == 0) load_col<n>(Xp, x);                 // row 0 never changes (zero or init_state)
+            else { load_col<n>(X2p + (size_t)t * n * TILE, x); store_col<n>(Xp + (size_t)t * n * TILE, x); }
+            load_col<m>(U2p + (size_t)t * m * TILE, u);
+            store_col<m>(Up + (size_t)t * m * TILE, u);
+            if (t == a.N - 1) {
+                double xN[n];
+                load_col<n>(X2p + (size_t)a.N * n * TILE, xN);
+                store_col<n>(Xp + (size_t)a.N * n * TILE, xN);
+            }
+        } else {
+            load_col<n>(Xp + (size_t)t * n * TILE, x);
+            load_col<m>(Up + (size_t)t * m * TILE, u);
+        }
+        double A[n * n], Bm[n * m];
+        S::A(x, u, a.dt, p, A);                                                        // :96
+        S::B(x, u, a.dt, p, Bm);                                                       // :97
+        double* l = Lp + (size_t)t * Lin<S>::n_lin * TILE;
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < n * n; ++i) if (S::a_kind(i) == 'x') { l[(size_t)e * TILE] = A[i]; ++e; }
+#pragma unroll
+        for (int i = 0; i < n * m; ++i) if (S::b_kind(i) == 'x') { l[(size_t)e * TILE] = Bm[i]; ++e; }
+    }
+}
+
+template <class S>
+__device__ __forceinline__ void load_lin(const double* l, double (&A)[S::n * S::n], double (&Bm)[S::n * S::m])
+{
+    constexpr int n = S::n, m = S::m;
+    int e = 0;
+#pragma unroll
+    for (int i = 0; i < n * n; ++i) {
+        const char kd = S::a_kind(i);
+        if (kd == 'x') { A[i] = l[(size_t)e * TILE]; ++e; } else A[i] = kd == '1' ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < n * m; ++i) {
+        const char kd = S::b_kind(i);
+        if (kd == 'x') { Bm[i] = l[(size_t)e * TILE]; ++e; } else Bm[i] = kd == '1' ? 1.0 : 0.0;
+    }
+}
+
+#ifndef RICCATI_GRP_WAVES
+#define RICCATI_GRP_WAVES 2
+#endif
+#ifndef RICCATI_PREFETCH
+#define RICCATI_PREFETCH 4
+#endif
+template <class S>
+__global__ void __launch_bounds__(64) k_riccati(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m;
+    const long long tile = a.tile0 + blockIdx.x;
+    const int lane = threadIdx.x;
+    const long long b = tile * TILE + lane;
+    const bool act = a.active[b] != 0;
+    if (__ballot(act) == 0ull) return;
+    double target[n], Qk[n * n], Rk[m * m], Vx[n], Vxx[n * n];
+    load_col<n>(a.TARGET + (size_t)tile * n * TILE + lane, target);
+    load_uniform<n * n>(a.WTS, Qk);
+    load_uniform<m * m>(a.WTS + n * n, Rk);
+    load_uniform<n * n>(a.WTS + n * n + m * m, Vxx);                                   // :67
+    const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
+    const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+    const double* Lp = a.LIN + (size_t)tile * a.N * Lin<S>::n_lin * TILE + lane;
+    double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + lane;
+    double* kp = a.KFF + (size_t)tile * a.N * m * TILE + lane;
+    terminal_value<S>(Xp + (size_t)a.N * n * TILE, target, Vxx, Vx);
+    double ecr = 0.0, ecr_g = 0.0, ecr_h = 0.0;
+    bool ok = true;
+    // A_t, B_t, u_t of the next D steps are in flight while step t computes: one step (~0.5 us of dependent arithmetic)
+    // is shorter than an HBM round trip, and one wave per SIMD has nothing else to hide it behind.
+    constexpr int D = Lin<S>::n_lin + m <= 16 ? RICCATI_PREFETCH : 1;
+    double Ar[D][n * n], Br[D][n * m], ur[D][m];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int tl = a.N - 1 - d > 0 ? a.N - 1 - d : 0;
+        load_lin<S>(Lp + (size_t)tl * Lin<S>::n_lin * TILE, Ar[d], Br[d]);
+        load_col<m>(Up + (size_t)tl * m * TILE, ur[d]);
+    }
+    for (int t0 = a.N - 1; t0 >= 0; t0 -= D) {                                         // :82
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int t = t0 - d;
+            if (t < 0) break;
+            double k[m], K[m * n], g, h;
+            ok = Riccati<S>::step(Ar[d], Br[d], ur[d], Qk, Rk, a.quu_reg, Vx, Vxx, k, K, g, h) && ok;
+            const int tl = t - D > 0 ? t - D : 0;                                      // slot d next holds step t - D
+            load_lin<S>(Lp + (size_t)tl * Lin<S>::n_lin * TILE, Ar[d], Br[d]);
+            load_col<m>(Up + (size_t)tl * m * TILE, ur[d]);
+            if (act) {
+                store_col<m>(kp + (size_t)t * m * TILE, k);                            // :111
+                store_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K);                  // :112
+            }
+            const double cur = g + h;                                                  // :117
+            ecr_g += g; ecr_h += h; ecr += cur;                                        // :119-121
+        }
+    }
+    if (act) backward_epilogue(a, tile, lane, b, ecr, ecr_g, ecr_h, ok);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_riccati_grp: the same recursion as k_riccati with a ROW of 16 lanes per problem (4 problems per wave), for
+// systems whose V_xx does not fit one lane's registers (n = 12: V_xx, Q_xx and A^T V_xx are 3 x 144 doubles).
+//   * lane r of a row keeps ROW r of A_t and of B_t in registers (gathered straight from LIN, next step in flight);
+//     between steps lane j holds COLUMN j of V_xx and V_x[j].
+//   * every product needs one operand that is the same for the whole row of lanes (A[r][i], K[l][j], V_x[r], ...).
+//     Those are never staged in LDS: the DPALU broadcast `v_fmac_f64_dpp ... row_newbcast:r` multiplies lane r's
+//     register into every lane of its row inside the FMA itself.  (The first version read them from LDS: 262 LDS
+//     instructions per step, and the CU's single LDS pipe -- shared by the four SIMDs -- was the bound, VALU 33 % busy.)
+//   * column phase (lane j): (A^T V_xx)[:, j], (B^T V_xx)[:, j] over the structural non-zeros; three small LDS
+//     transposes remain (A^T V_xx columns -> rows, A rows -> columns for Q_ux / Q_x, new V_xx rows -> columns);
+//   * row phase (lane i): row i of Q_xx = (A^T V_xx) A and of the four-term V_xx update (ilqr.py:125), column i of
+//     Q_ux and K, Q_x[i]; Q_uu, Q_u, the inverse and k are small and computed by every lane.
+// One wave per workgroup: the LDS hand-offs are ordered by program order (the barriers only pin the compiler).
+// Operation order follows the reference ((A^T V) A, (B^T V) A, ...), as Riccati<S>::step does.
+// ------------------------------------------------------------------------------------------------
+template <class S>
+struct Grp {
+    static constexpr int n = S::n, m = S::m;
+    static constexpr int GL = 16;                       // one DPP row
+    static constexpr int P = TILE / GL;                 // problems per wave
+    static constexpr int LD = n + 1;                    // padded leading dimension of the transpose buffers
+    static constexpr int oT = 0, oAT = oT + n * LD, SLOT = ((oAT + n * LD + 1) | 1);
+    static_assert(n <= GL, "k_riccati_grp: one lane per state");
+};
+
+// index of dense entry e of A (or B) in the step's LIN row; -1 structural zero, -2 structural one
+template <class S, bool IS_B>
+__device__ __forceinline__ int lin_index(const int e)
+{
+    constexpr int cnt_all = IS_B ? S::n * S::m : S::n * S::n;
+    int cnt = IS_B ? Lin<S>::nA : 0;
+    int res = -1;
+#pragma unroll
+    for (int q = 0; q < cnt_all; ++q) {
+        const char kd = IS_B ? S::b_kind(q) : S::a_kind(q);
+        if (q == e) res = kd == 'x' ? cnt : (kd == '1' ? -2 : -1);
+        if (kd == 'x') ++cnt;
+    }
+    return res;
+}
+
+// acc += (lane L of this lane's 16-lane row of `src`) * own.  The wait states a DPP read of a just-written VGPR needs
+// are not inserted around inline asm by the compiler, hence the s_nop.
+template <int L>
+__device__ __forceinline__ void fmac_row(double& acc, const double src, const double own)
+{
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(own), "n"(L));
+}
+template <int L>
+__device__ __forceinline__ double bcast_row(const double src)
+{
+    double r;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(L));
+    return r;
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <class S>
+__global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KArgs a)
+{
+    using G = Grp<S>;
+    constexpr int n = S::n, m = S::m, GL = G::GL, P = G::P, NL = Lin<S>::n_lin, LD = G::LD;
+    __shared__ double sh[P * G::SLOT + n * n];
+    const int lane = threadIdx.x;
+    const int grp = lane / GL, c = lane % GL;
+    // The 16 workgroups of a tile touch the same 128-byte lines (4 problems = 32 bytes of each): workgroups are dealt
+    // round-robin over the 8 XCDs, so logical ids are chosen such that a tile's workgroups share one XCD's L2.
+    const unsigned pb = blockIdx.x, nb8 = gridDim.x & ~7u;
+    const unsigned lb = pb < nb8 ? (pb & 7u) * (nb8 >> 3) + (pb >> 3) : pb;
+    const long long b = a.tile0 * TILE + (long long)lb * P + grp;
+    const long long tile = b >> 6;
+    const int pl = (int)(b & 63);
+    const bool act = a.active[b] != 0;
+    if (__ballot(act) == 0ull) return;
+    double* s = sh + grp * G::SLOT;
+    const bool row = c < n;
+    const int cc = row ? c : n - 1;                     // surplus lanes shadow the last row / column and never store
+    // where row cc of A_t / B_t sits in a LIN record: byte offsets of the general entries (structural zeros and ones
+    // load a harmless valid entry instead; their constants are written to the transpose buffer once, below)
+    int aoff[n], boff[m];
+    unsigned amask = 0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+        const int q = lin_index<S, false>(cc * n + i);
+        aoff[i] = (q > 0 ? q : 0) * (TILE * (int)sizeof(double));
+        amask |= (q >= 0 ? 1u : 0u) << i;
+        if (row && q < 0) s[G::oAT + i * LD + c] = q == -2 ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int l = 0; l < m; ++l) {
+        const int q = lin_index<S, true>(cc * m + l);
+        boff[l] = (q > 0 ? q : 0) * (TILE * (int)sizeof(double));
+    }
+    double Rk[m * m], Vc[n], vx;
+    double* sQk = sh + P * G::SLOT;                                                    // Q_k, shared by the rows
+    for (int e = lane; e < n * n; e += TILE) sQk[e] = a.WTS[e];
+    load_uniform<m * m>(a.WTS + n * n, Rk);
+    const double* QT = a.WTS + n * n + m * m;
+#pragma unroll
+    for (int r = 0; r < n; ++r) Vc[r] = QT[r * n + cc];                                // :67 column j of Q_T
+    const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + pl;
+    const double* Up = a.U + (size_t)tile * a.N * m * TILE + pl;
+    const double* Lp = a.LIN + (size_t)tile * a.N * NL * TILE + pl;
+    double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + pl;
+    double* kp = a.KFF + (size_t)tile * a.N * m * TILE + pl;
+    {
+        double target[n], xN[n];
+        load_col<n>(a.TARGET + (size_t)tile * n * TILE + pl, target);
+        load_col<n>(Xp + (size_t)a.N * n * TILE, xN);
+        double acc = 0.0;                                                              // :68-70 V_x[j] = (Q_T ed)[j]
+#pragma unroll
+        for (int q = 0; q < n; ++q) acc = __builtin_fma(QT[cc * n + q], xN[q] - target[q], acc);
+        vx = acc;
+    }
+    auto load_rows = [&](int t, double (&Ar)[n], double (&Br)[m], double (&u)[m]) {
+        const char* l = (const char*)(Lp + (size_t)t * NL * TILE);
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            int o = aoff[i];
+            asm volatile("" : "+v"(o));                  // keep base + offset out of the loop-invariant (spilled) set
+            Ar[i] = *(const double*)(l + o);
+        }
+#pragma unroll
+        for (int q = 0; q < m; ++q) {
+            int o = boff[q];
+            asm volatile("" : "+v"(o));
+            Br[q] = *(const double*)(l + o);
+        }
+#pragma unroll
+        for (int q = 0; q < m; ++q) u[q] = Up[((size_t)t * m + q) * TILE];
+    };
+    double ecr = 0.0, ecr_g = 0.0, ecr_h = 0.0;
+    bool ok = true;
+    __syncthreads();
+    // one time step with rows (Ar, Br, u) of step t in registers; the rows of step t-1 are requested into (An, Bn, un)
+    auto step = [&](const int t, const double (&Ar)[n], const double (&Br)[m], const double (&u)[m], double (&An)[n],
+                    double (&Bn)[m], double (&un)[m]) {
+        load_rows(t > 0 ? t - 1 : 0, An, Bn, un);
+        // ---- column phase (lane j): A^T V_xx and B^T V_xx, column j
+        double AtV[n], BtV[m];
+#pragma unroll
+        for (int i = 0; i < n; ++i) AtV[i] = 0.0;
+#pragma unroll
+        for (int l = 0; l < m; ++l) BtV[l] = 0.0;
+        static_for<0, n>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            static_for<0, n>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr char kd = S::A_pat[r * n + i];
+                if constexpr (kd == 'x') fmac_row<r>(AtV[i], Ar[i], Vc[r]);            // A[r][i] * V[r][j]
+                else if constexpr (kd == '1') AtV[i] = AtV[i] + Vc[r];
+            });
+            static_for<0, m>([&](auto lc) {
+                constexpr int l = decltype(lc)::value;
+                constexpr char kd = S::B_pat[r * m + l];
+                if constexpr (kd == 'x') fmac_row<r>(BtV[l], Br[l], Vc[r]);            // B[r][l] * V[r][j]
+                else if constexpr (kd == '1') BtV[l] = BtV[l] + Vc[r];
+            });
+        });
+        if (row) {
+#pragma unroll
+            for (int i = 0; i < n; ++i) {
+                s[G::oT + i * LD + c] = AtV[i];
+                if ((amask >> i) & 1u) s[G::oAT + i * LD + c] = Ar[i];
+            }
+        }
+        __syncthreads();
+        // ---- gains (every lane: Q_uu, Q_u, the inverse, k; lane i: column i of Q_ux and K, Q_x[i]).  Done before the
+        // row phase so that Q_uu and its inverse (2 m^2 doubles) are dead when the rows of A^T V_xx come into registers.
+        double Qux[m], Qu[m], k[m], Kc[m], KtQuu[m], g = 0.0, h = 0.0;
+        {
+            double Quu[m * m], Quu_inv[m * m], Acol[n], Qx = 0.0;
+#pragma unroll
+            for (int r = 0; r < n; ++r) Acol[r] = s[G::oAT + cc * LD + r];             // A[r][i]
+#pragma unroll
+            for (int q = 0; q < m * m; ++q) Quu[q] = 0.0;
+#pragma unroll
+            for (int l = 0; l < m; ++l) Qu[l] = 0.0;
+#pragma unroll
+            for (int l = 0; l < m; ++l) Qux[l] = 0.0;
+            static_for<0, n>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                static_for<0, m>([&](auto l2c) {
+                    constexpr int l2 = decltype(l2c)::value;
+                    constexpr char kd = S::B_pat[r * m + l2];
+                    if constexpr (kd == 'x') {
+                        const double Brl = bcast_row<r>(Br[l2]);                       // B[r][l2], the same in every lane
+#pragma unroll
+                        for (int l = 0; l < m; ++l) fmac_row<r>(Quu[l * m + l2], BtV[l], Brl);       // :102
+                        fmac_row<r>(Qu[l2], vx, Brl);                                  // :100 B[r][l2] * V_x[r]
+                    } else if constexpr (kd == '1') {
+#pragma unroll
+                        for (int l = 0; l < m; ++l) Quu[l * m + l2] = Quu[l * m + l2] + bcast_row<r>(BtV[l]);
+                        Qu[l2] = Qu[l2] + bcast_row<r>(vx);
+                    }
+                });
+#pragma unroll
+                for (int l = 0; l < m; ++l) fmac_row<r>(Qux[l], BtV[l], Acol[r]);       // :101 (B^T V_xx)[l][r] * A[r][i]
+                fmac_row<r>(Qx, vx, Acol[r]);                                          // :99  A[r][i] * V_x[r]
+            });
+#pragma unroll
+            for (int l = 0; l < m; ++l) {
+#pragma unroll
+                for (int l2 = 0; l2 < m; ++l2) Quu[l * m + l2] = Rk[l * m + l2] + Quu[l * m + l2];
+                Quu[l * m + l] += a.quu_reg;
+            }
+#pragma unroll
+            for (int l = 0; l < m; ++l) {                                              // :93 l_u = R_k u
+                double lu = 0.0;
+#pragma unroll
+                for (int l2 = 0; l2 < m; ++l2) lu = __builtin_fma(Rk[l * m + l2], u[l2], lu);
+                Qu[l] = lu + Qu[l];
+            }
+                ok = Riccati<S>::inv_spd(Quu, Quu_inv) && ok;                              // :106
+    #pragma unroll
+            for (int l = 0; l < m; ++l) {                                              // :107-108
+                double acc = 0.0, acc2 = 0.0;
+#pragma unroll
+                for (int l2 = 0; l2 < m; ++l2) {
+                    acc = __builtin_fma(-Quu_inv[l * m + l2], Qu[l2], acc);
+                    acc2 = __builtin_fma(-Quu_inv[l * m + l2], Qux[l2], acc2);
+                }
+                k[l] = acc;
+                Kc[l] = acc2;
+            }
+#pragma unroll
+            for (int l = 0; l < m; ++l) g = __builtin_fma(-Qu[l], k[l], g);            // :115
+#pragma unroll
+            for (int l = 0; l < m; ++l) {                                              // :116
+                double acc = 0.0;
+#pragma unroll
+                for (int l2 = 0; l2 < m; ++l2) acc = __builtin_fma(0.5 * k[l2], Quu[l2 * m + l], acc);
+                h = __builtin_fma(acc, k[l], h);
+            }
+#pragma unroll
+            for (int l = 0; l < m; ++l) {
+                double acc = 0.0;
+#pragma unroll
+                for (int l2 = 0; l2 < m; ++l2) acc = __builtin_fma(Kc[l2], Quu[l2 * m + l], acc);
+                KtQuu[l] = acc;
+            }
+            double v1 = 0.0, v2 = 0.0, v3 = 0.0;                                       // :124
+#pragma unroll
+            for (int l = 0; l < m; ++l) v1 = __builtin_fma(KtQuu[l], k[l], v1);
+#pragma unroll
+            for (int l = 0; l < m; ++l) v2 = __builtin_fma(Kc[l], Qu[l], v2);
+#pragma unroll
+            for (int l = 0; l < m; ++l) v3 = __builtin_fma(Qux[l], k[l], v3);
+            vx = ((Qx + v1) + v2) + v3;
+        }
+        if (act) {
+            if (row) {
+#pragma unroll
+                for (int l = 0; l < m; ++l) Kp[((size_t)t * (m * n) + l * n + c) * TILE] = Kc[l];   // :112
+            }
+#pragma unroll
+            for (int l = 0; l < m; ++l) if (c == l) kp[((size_t)t * m + l) * TILE] = k[l];          // :111
+        }
+        const double cur = g + h;                                                      // :117
+        ecr_g += g; ecr_h += h; ecr += cur;                                            // :119-121
+        // ---- row phase (lane i): row i of Q_xx (:103) and of the new V_xx (:125), one entry at a time, written
+        // straight into the lane's own row of the transpose buffer (whose old contents are in Ri by then)
+        double Ri[n], Aw[n];
+#pragma unroll
+        for (int r = 0; r < n; ++r) Ri[r] = s[G::oT + cc * LD + r];                    // (A^T V_xx)[i][:]
+#pragma unroll
+        for (int j = 0; j < n; ++j) Aw[j] = s[G::oAT + j * LD + cc];                   // own row of A_t again (its
+        static_for<0, n>([&](auto jc) {                                                // registers ended with the column phase)
+            constexpr int j = decltype(jc)::value;
+            double acc = 0.0;
+            static_for<0, n>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                constexpr char kd = S::A_pat[r * n + j];
+                if constexpr (kd == 'x') fmac_row<r>(acc, Aw[j], Ri[r]);               // (A^T V_xx)[i][r] * A[r][j]
+                else if constexpr (kd == '1') acc = acc + Ri[r];
+            });
+            const double Qxx = sQk[cc * n + j] + acc;
+            double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+            for (int l = 0; l < m; ++l) fmac_row<j>(t1, Kc[l], Qux[l]);                // Q_ux[l][i] * K[l][j]
+#pragma unroll
+            for (int l = 0; l < m; ++l) fmac_row<j>(t2, Qux[l], Kc[l]);                // K[l][i] * Q_ux[l][j]
+#pragma unroll
+            for (int l = 0; l < m; ++l) fmac_row<j>(t3, Kc[l], KtQuu[l]);              // (K^T Q_uu)[i][l] * K[l][j]
+            const double Vij = ((Qxx + t1) + t2) + t3;
+            if (row) s[G::oT + c * LD + j] = Vij;                                      // rows -> columns, part 1
+        });
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < n; ++r) Vc[r] = s[G::oT + r * LD + cc];
+        __syncthreads();
+    };
+    double A0[n], B0[m], u0[m], A1[n], B1[m], u1[m];
+    load_rows(a.N - 1, A0, B0, u0);
+    for (int t = a.N - 1; t >= 0; t -= 2) {                                            // :82
+        step(t, A0, B0, u0, A1, B1, u1);
+        if (t > 0) step(t - 1, A1, B1, u1, A0, B0, u0);
+    }
+    if (act && c == 0) backward_epilogue(a, tile, pl, b, ecr, ecr_g, ecr_h, ok);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_ltvlqr: ltvlqr.py:3-28.  One lane per problem; P stays in VGPRs.
+// K = -inv(R + B'PB) B'PA,  P <- Q + A'PA - (A'PB) inv(R + B'PB) (B'PA)
+// ------------------------------------------------------------------------------------------------
+template <class S>
+__global__ void __launch_bounds__(64) k_ltvlqr(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m, np = S::np;
+    const long long tile = a.tile0 + blockIdx.x;
+    const int lane = threadIdx.x;
+    double p[np], Qk[n * n], Rk[m * m], P[n * n];
+    load_col<np>(a.PARAMS + (size_t)tile * np * TILE + lane, p);
+    load_uniform<n * n>(a.WTS, Qk);
+    load_uniform<m * m>(a.WTS + n * n, Rk);
+    load_uniform<n * n>(a.WTS + n * n + m * m, P);                                     // :14
+    const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
+    const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+    double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + lane;
+    bool ok = true;
+    // ring of D trajectory rows in flight (as in k_riccati): at 65 536 problems every SIMD holds one wave, and one step
+    // of dependent arithmetic is shorter than an HBM round trip
+    constexpr int D = (n + m) <= 8 ? RICCATI_PREFETCH : 1;
+    double xr[D][n], ur[D][m];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int tl = a.N - 1 - d > 0 ? a.N - 1 - d : 0;
+        load_col<n>(Xp + (size_t)tl * n * TILE, xr[d]);
+        load_col<m>(Up + (size_t)tl * m * TILE, ur[d]);
+    }
+    for (int t0 = a.N - 1; t0 >= 0; t0 -= D) {                                         // :15
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int t = t0 - d;
+        if (t < 0) break;
+        double x[n], u[m];
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = xr[d][i];
+#pragma unroll
+        for (int j = 0; j < m; ++j) u[j] = ur[d][j];
+        double A[n * n], Bm[n * m];
+        S::A(x, u, a.dt, p, A);                                                        // :21
+        S::B(x, u, a.dt, p, Bm);                                                       // :22
+        {
+            const int tl = t - D > 0 ? t - D : 0;                                      // slot d next holds step t - D
+            load_col<n>(Xp + (size_t)tl * n * TILE, xr[d]);
+            load_col<m>(Up + (size_t)tl * m * TILE, ur[d]);
+        }
+        double BtP[m * n], BtPA[m * n], G[m * m], Gi[m * m], K[m * n];
+#pragma unroll
+        for (int j = 0; j < m; ++j)
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::b_kind(r * m + j), Bm[r * m + j], P[r * n + c]);
+                BtP[j * n + c] = s;
+            }
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::a_kind(r * n + c), A[r * n + c], BtP[j * n + r]);
+                BtPA[j * n + c] = s;
+            }
+#pragma unroll
+            for (int l = 0; l < m; ++l) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::b_kind(r * m + l), Bm[r * m + l], BtP[j * n + r]);
+                G[j * m + l] = Rk[j * m + l] + s;
+            }
+        }
+        ok = Riccati<S>::inv_spd(G, Gi) && ok;
+#pragma unroll
+        for (int j = 0; j < m; ++j)
+#pragma unroll
+            for (int c = 0; c < n; ++c) {                                              // :24
+                double s = 0.0;
+#pragma unroll
+                for (int l = 0; l < m; ++l) s = __builtin_fma(-Gi[j * m + l], BtPA[l * n + c], s);
+                K[j * n + c] = s;
+            }
+        store_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K);                          // :25
+        // :27  P = Q + A'PA - (A'PB) Gi (B'PA);  (A'PB)[i][l] is formed from the rows of A'P
+        double Pn[n * n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double row[n], apb[m];
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::a_kind(r * n + i), A[r * n + i], P[r * n + c]);
+                row[c] = s;
+            }
+#pragma unroll
+            for (int l = 0; l < m; ++l) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::b_kind(r * m + l), Bm[r * m + l], row[r]);
+                apb[l] = s;
+            }
+            double w[m];                                                               // (A'PB Gi)[i][:]
+#pragma unroll
+            for (int l = 0; l < m; ++l) {
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < m; ++q) s = __builtin_fma(apb[q], Gi[q * m + l], s);
+                w[l] = s;
+            }
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::a_kind(r * n + c), A[r * n + c], row[r]);
+                double corr = 0.0;
+#pragma unroll
+                for (int l = 0; l < m; ++l) corr = __builtin_fma(w[l], BtPA[l * n + c], corr);
+                Pn[i * n + c] = (Qk[i * n + c] + s) - corr;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < n * n; ++i) P[i] = Pn[i];
+      }
+    }
+    if (!ok) a.status[tile * TILE + lane] = ILQR_STATUS_NUMERICAL;
+}
+

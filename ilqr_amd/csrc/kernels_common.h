@@ -1,0 +1,354 @@
+// kernels_common.h -- tile constants, the compiled systems, kernel arguments, the per-step Riccati algebra, small load/store helpers
+// Part of ilqr_hip.hip (included inside its anonymous namespace, in this order: kernels_common.h,
+// kernels_backward.h, kernels_forward.h, kernels_util.h); not a stand-alone header.
+
+constexpr int TILE = 64;          // problems per tile = lanes per wavefront
+constexpr int MAX_TRIALS = 64;    // line-search trials kept in the alpha table
+constexpr int N_KERNEL_IDS = 8;
+
+// ------------------------------------------------------------------------------------------------
+// systems
+// ------------------------------------------------------------------------------------------------
+#define ILQR_DEFINE_SYSTEM(NAME, UP)                                                                              \
+    struct Sys_##NAME {                                                                                           \
+        static constexpr int n = ILQR_DYN_##UP##_N, m = ILQR_DYN_##UP##_M, np = ILQR_DYN_##UP##_NP;               \
+        static constexpr int id = ILQR_DYN_##UP##_ID;                                                             \
+        static constexpr const char* A_pat = ilqr_dyn_##NAME##_A_pat;                                             \
+        static constexpr const char* B_pat = ilqr_dyn_##NAME##_B_pat;                                             \
+        static __device__ __forceinline__ char a_kind(int i) { return ilqr_dyn_##NAME##_A_pat[i]; }               \
+        static __device__ __forceinline__ char b_kind(int i) { return ilqr_dyn_##NAME##_B_pat[i]; }               \
+        static __device__ __forceinline__ void f(const double* x, const double* u, double dt, const double* p,   \
+                                                 double* o) { ilqr_dyn_##NAME##_f(x, u, dt, p, o); }              \
+        static __device__ __forceinline__ void A(const double* x, const double* u, double dt, const double* p,   \
+                                                 double* o) { ilqr_dyn_##NAME##_A(x, u, dt, p, o); }              \
+        static __device__ __forceinline__ void B(const double* x, const double* u, double dt, const double* p,   \
+                                                 double* o) { ilqr_dyn_##NAME##_B(x, u, dt, p, o); }              \
+    };
+ILQR_DEFINE_SYSTEM(pendulum, PENDULUM)
+ILQR_DEFINE_SYSTEM(acrobot, ACROBOT)
+ILQR_DEFINE_SYSTEM(cartpole, CARTPOLE)
+ILQR_DEFINE_SYSTEM(quadcopter, QUADCOPTER)
+ILQR_DEFINE_SYSTEM(car, CAR)
+ILQR_DEFINE_SYSTEM(double_integrator, DOUBLE_INTEGRATOR)
+ILQR_DEFINE_SYSTEM(double_pendulum, DOUBLE_PENDULUM)
+
+struct SysInfo { const char* name; int n, m, np; };
+constexpr int N_SYSTEMS = 7;
+const SysInfo SYSTEMS[N_SYSTEMS] = {{"pendulum", 2, 1, 3}, {"acrobot", 4, 1, 5}, {"cartpole", 4, 1, 4}, {"quadcopter", 12, 4, 8},
+                                    {"car", 4, 2, 1}, {"double_integrator", 2, 1, 1}, {"double_pendulum", 4, 2, 5}};
+
+// ------------------------------------------------------------------------------------------------
+// kernel arguments
+// ------------------------------------------------------------------------------------------------
+struct KArgs {
+    int N;                 // time steps
+    int it;                // outer iteration index (trace row)
+    int n_iter;            // rows in trace
+    int zero_first;
+    int n_trials;          // line-search trials with alpha > low_learning_rate
+    int state_rows;        // rows per problem in X (N+1)
+    long long n_tiles;     // tiles this launch covers (a sub-batch of the workspace)
+    long long tile0;       // first tile of the sub-batch
+    double dt, low_red, armijo_thr, quu_reg;
+    double* X;             // [tile][state_rows][n][64]
+    double* U;             // [tile][N][m][64]
+    const double* G;       // [tile][N][m][64] initial guess (read by k_rollout only)
+    double* KFB;           // [tile][N][m*n][64]
+    double* KFF;           // [tile][N][m][64]
+    double* X2;            // split pipeline: accepted trajectory before it is copied back, same layout as X / U
+    double* U2;
+    double* CKPT;          // [problem][segment][n][64 trial slots] line-search checkpoints
+    double* LIN;           // [tile][N][nA_x + nB_x][64] general entries of A_t, B_t
+    int ck;                // checkpoint interval (time steps per segment)
+    int n_seg;             // segments = ceil(N / ck)
+    double* XO;            // forward outputs (may alias X/U)
+    double* UO;
+    const double* INIT;    // [tile][n][64]
+    const double* TARGET;  // [tile][n][64]
+    const double* PARAMS;  // [tile][np][64]
+    const double* WTS;     // Qk[n*n], Rk[m*m], QT[n*n]
+    const double* alphas;  // [MAX_TRIALS] alpha_j by repeated multiplication
+    const double* alpha_pp;// per-problem alpha (forward API) or nullptr
+    double* cost;          // [Bpad]
+    double* new_cost;      // [Bpad]
+    double* dJ;            // [tile][3][64]: total, grad, hess
+    int* active;           // [Bpad]
+    int* iters;
+    int* status;
+    int* acc_j;
+    int* ls_rounds;
+    int ls_round;          // line search: round r evaluates trials [r*W, r*W + W)
+    int* ls_list;          // [2][Bpad] problems still searching after a round (ping-pong by round parity)
+    int* ls_count;         // [MAX_TRIALS] length of the list each round leaves (zeroed before round 0)
+    int* accepts;
+    double* trace;         // [tile][n_iter][6][64] or nullptr
+    long long Bpad;
+};
+
+// ------------------------------------------------------------------------------------------------
+// small dense helpers.  Every loop is fully unrolled so all arrays live in VGPRs; `kind` is the
+// compile-time sparsity class of the Jacobian entry ('0' zero, '1' one, 'x' general): after unrolling
+// the tests fold away and structurally zero / unit entries cost nothing.  Skipping an exact-zero product
+// or multiplying by an exact one does not change any rounding.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void acc_term(double& s, bool& first, char kind, double a, double b)
+{
+    if (kind == '0') return;
+    if (kind == '1') s = first ? b : s + b;
+    else s = first ? a * b : __builtin_fma(a, b, s);
+    first = false;
+}
+
+template <class S>
+struct Riccati {
+    static constexpr int n = S::n, m = S::m;
+
+    // inverse of the m x m matrix Q (row-major).  m == 1: reciprocal (what LAPACK getri does for 1x1).
+    // m > 1: Cholesky L L^T, inv = L^-T L^-1.  Returns false when Q is not positive definite / not finite.
+    static __device__ __forceinline__ bool inv_spd(const double (&Q)[m * m], double (&Qi)[m * m])
+    {
+        if constexpr (m == 1) {
+            Qi[0] = 1.0 / Q[0];
+            return Q[0] != 0.0;
+        } else {
+            // 1 / L_jj is computed once per pivot (IEEE division) and reused for the diagonal of L^-1.  The off-diagonal
+            // divisions stay divisions: replacing them by reciprocal multiplies moved the quadcopter's final K from
+            // < 1e-8 to 2.5e-8 of the reference after 21 iterations (the inverse is where rounding is amplified most).
+            double L[m * m], Li[m * m], rinv[m];
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < m; ++j) {
+                double d = Q[j * m + j];
+#pragma unroll
+                for (int q = 0; q < j; ++q) d = __builtin_fma(-L[j * m + q], L[j * m + q], d);
+                ok = ok && (d > 0.0);
+                const double ljj = sqrt(d);
+                L[j * m + j] = ljj;
+                const double r = 1.0 / ljj;
+                rinv[j] = r;
+#pragma unroll
+                for (int i = j + 1; i < m; ++i) {
+                    double s = Q[i * m + j];
+#pragma unroll
+                    for (int q = 0; q < j; ++q) s = __builtin_fma(-L[i * m + q], L[j * m + q], s);
+                    L[i * m + j] = s * r;
+                }
+            }
+            // Li = L^-1 (lower triangular)
+#pragma unroll
+            for (int j = 0; j < m; ++j) {
+                Li[j * m + j] = rinv[j];
+#pragma unroll
+                for (int i = j + 1; i < m; ++i) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int q = j; q < i; ++q) s = __builtin_fma(-L[i * m + q], Li[q * m + j], s);
+                    Li[i * m + j] = s / L[i * m + i];
+                }
+            }
+            // inv = Li^T Li
+#pragma unroll
+            for (int i = 0; i < m; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int q = i; q < m; ++q) s = __builtin_fma(Li[q * m + i], Li[q * m + j], s);
+                    Qi[i * m + j] = s;
+                    Qi[j * m + i] = s;
+                }
+            return ok;
+        }
+    }
+
+    // One step of ilqr.backwards_pass (ilqr.py:84-125).  A, Bm: Jacobians at (x_t,u_t).  Updates Vx, Vxx in place,
+    // returns k, K and the step's (grad, hess) expected-reduction terms.
+    static __device__ __forceinline__ bool step(const double (&A)[n * n], const double (&Bm)[n * m], const double (&u)[m],
+                                                const double (&Qk)[n * n], const double (&Rk)[m * m], double quu_reg,
+                                                double (&Vx)[n], double (&Vxx)[n * n], double (&k)[m], double (&K)[m * n],
+                                                double& g_out, double& h_out)
+    {
+        double Qx[n], Qu[m], BtV[m * n], Qux[m * n], Quu[m * m], Qxx[n * n], Quu_inv[m * m];
+        // :99  Q_x = A.T @ V_x   (l_x = Q_k @ 0 = 0)
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double s = 0.0; bool first = true;
+#pragma unroll
+            for (int r = 0; r < n; ++r) acc_term(s, first, S::a_kind(r * n + i), A[r * n + i], Vx[r]);
+            Qx[i] = s;
+        }
+        // :93,:100  Q_u = R_k @ u + B.T @ V_x
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+            double lu = 0.0;
+#pragma unroll
+            for (int l = 0; l < m; ++l) lu = __builtin_fma(Rk[j * m + l], u[l], lu);
+            double s = 0.0; bool first = true;
+#pragma unroll
+            for (int r = 0; r < n; ++r) acc_term(s, first, S::b_kind(r * m + j), Bm[r * m + j], Vx[r]);
+            Qu[j] = lu + s;
+        }
+        // B.T @ V_xx
+#pragma unroll
+        for (int j = 0; j < m; ++j)
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::b_kind(r * m + j), Bm[r * m + j], Vxx[r * n + c]);
+                BtV[j * n + c] = s;
+            }
+        // :101  Q_ux = (B.T V_xx) A ; :102  Q_uu = R + (B.T V_xx) B
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::a_kind(r * n + c), A[r * n + c], BtV[j * n + r]);
+                Qux[j * n + c] = s;
+            }
+#pragma unroll
+            for (int l = 0; l < m; ++l) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::b_kind(r * m + l), Bm[r * m + l], BtV[j * n + r]);
+                Quu[j * m + l] = Rk[j * m + l] + s;
+            }
+            Quu[j * m + j] += quu_reg;
+        }
+        // :103  Q_xx = Q_k + (A.T V_xx) A, one row of A.T V_xx at a time
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double row[n];
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::a_kind(r * n + i), A[r * n + i], Vxx[r * n + c]);
+                row[c] = s;
+            }
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::a_kind(r * n + c), A[r * n + c], row[r]);
+                Qxx[i * n + c] = Qk[i * n + c] + s;
+            }
+        }
+        // :106-108  gains
+        const bool ok = inv_spd(Quu, Quu_inv);
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < m; ++l) s = __builtin_fma(-Quu_inv[j * m + l], Qu[l], s);
+            k[j] = s;
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double t = 0.0;
+#pragma unroll
+                for (int l = 0; l < m; ++l) t = __builtin_fma(-Quu_inv[j * m + l], Qux[l * n + c], t);
+                K[j * n + c] = t;
+            }
+        }
+        // :115-116  expected reduction terms
+        double g = 0.0, h = 0.0;
+#pragma unroll
+        for (int j = 0; j < m; ++j) g = __builtin_fma(-Qu[j], k[j], g);
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < m; ++i) s = __builtin_fma(0.5 * k[i], Quu[i * m + j], s);
+            h = __builtin_fma(s, k[j], h);
+        }
+        g_out = g; h_out = h;
+        // :124-125  value function update (four-term forms, no symmetrisation)
+        double KtQuu[n * m];
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+#pragma unroll
+            for (int l = 0; l < m; ++l) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < m; ++j) s = __builtin_fma(K[j * n + i], Quu[j * m + l], s);
+                KtQuu[i * m + l] = s;
+            }
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double v1 = 0.0, v2 = 0.0, v3 = 0.0;
+#pragma unroll
+            for (int l = 0; l < m; ++l) v1 = __builtin_fma(KtQuu[i * m + l], k[l], v1);
+#pragma unroll
+            for (int j = 0; j < m; ++j) v2 = __builtin_fma(K[j * n + i], Qu[j], v2);
+#pragma unroll
+            for (int j = 0; j < m; ++j) v3 = __builtin_fma(Qux[j * n + i], k[j], v3);
+            Vx[i] = ((Qx[i] + v1) + v2) + v3;
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+                for (int j = 0; j < m; ++j) t1 = __builtin_fma(Qux[j * n + i], K[j * n + c], t1);
+#pragma unroll
+                for (int j = 0; j < m; ++j) t2 = __builtin_fma(K[j * n + i], Qux[j * n + c], t2);
+#pragma unroll
+                for (int l = 0; l < m; ++l) t3 = __builtin_fma(KtQuu[i * m + l], K[l * n + c], t3);
+                Vxx[i * n + c] = ((Qxx[i * n + c] + t1) + t2) + t3;
+            }
+        }
+        return ok;
+    }
+};
+
+// stage cost of compute_cost (ilqr.py:56): (u^T R) u
+template <int m>
+__device__ __forceinline__ double input_cost(const double (&u)[m], const double (&Rk)[m * m])
+{
+    double c = 0.0;
+#pragma unroll
+    for (int j = 0; j < m; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < m; ++i) s = __builtin_fma(u[i], Rk[i * m + j], s);
+        c = __builtin_fma(s, u[j], c);
+    }
+    return c;
+}
+// terminal cost (ilqr.py:59-60): d = target - x_N, (d^T Q_T) d
+template <int n>
+__device__ __forceinline__ double terminal_cost(const double (&x)[n], const double (&target)[n], const double (&QT)[n * n])
+{
+    double d[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) d[i] = target[i] - x[i];
+    double c = 0.0;
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) s = __builtin_fma(d[i], QT[i * n + j], s);
+        c = __builtin_fma(s, d[j], c);
+    }
+    return c;
+}
+
+template <int CNT>
+__device__ __forceinline__ void load_col(const double* __restrict__ base, double (&out)[CNT])
+{
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) out[i] = base[(size_t)i * TILE];
+}
+template <int CNT>
+__device__ __forceinline__ void store_col(double* __restrict__ base, const double (&v)[CNT])
+{
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) base[(size_t)i * TILE] = v[i];
+}
+template <int CNT>
+__device__ __forceinline__ void load_uniform(const double* __restrict__ base, double (&out)[CNT])
+{
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) out[i] = base[i];
+}
+

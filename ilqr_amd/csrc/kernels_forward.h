@@ -1,0 +1,470 @@
+// kernels_forward.h -- forward side: k_rollout, k_cost, the closed-loop rollouts, k_linesearch, k_forward, k_accept_par (ilqr.py:30-62, 137-207)
+// Part of ilqr_hip.hip (included inside its anonymous namespace, in this order: kernels_common.h,
+// kernels_backward.h, kernels_forward.h, kernels_util.h); not a stand-alone header.
+// ------------------------------------------------------------------------------------------------
+// k_rollout: ilqr.py:30-47 with compute_cost (:49-62) fused.  One lane per problem, one wave per tile.
+// ------------------------------------------------------------------------------------------------
+template <class S>
+__global__ void __launch_bounds__(64) k_rollout(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m, np = S::np;
+    const long long tile = a.tile0 + blockIdx.x;
+    const int lane = threadIdx.x;
+    const long long b = tile * TILE + lane;
+    double x[n], p[np], target[n], Rk[m * m], QT[n * n];
+    load_col<n>(a.INIT + (size_t)tile * n * TILE + lane, x);
+    load_col<np>(a.PARAMS + (size_t)tile * np * TILE + lane, p);
+    load_col<n>(a.TARGET + (size_t)tile * n * TILE + lane, target);
+    load_uniform<m * m>(a.WTS + n * n, Rk);
+    load_uniform<n * n>(a.WTS + n * n + m * m, QT);
+    double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
+    const double* Gp = a.G + (size_t)tile * a.N * m * TILE + lane;
+    double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+    {
+        double x0[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) x0[i] = a.zero_first ? 0.0 : x[i];
+        store_col<n>(Xp, x0);
+    }
+    double cost = 0.0;
+    for (int t = 0; t < a.N; ++t) {
+        double u[m], xn[n];
+        load_col<m>(Gp + (size_t)t * m * TILE, u);
+        cost = cost + input_cost<m>(u, Rk);
+        S::f(x, u, a.dt, p, xn);
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = xn[i];
+        store_col<n>(Xp + (size_t)(t + 1) * n * TILE, x);                              // :39
+        store_col<m>(Up + (size_t)t * m * TILE, u);                                    // :40
+    }
+    cost = cost + terminal_cost<n>(x, target, QT);
+    a.cost[b] = cost;
+}
+
+// k_cost: compute_cost (ilqr.py:49-62) of the stored trajectory.
+template <class S>
+__global__ void __launch_bounds__(64) k_cost(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m;
+    const long long tile = a.tile0 + blockIdx.x;
+    const int lane = threadIdx.x;
+    double x[n], target[n], Rk[m * m], QT[n * n];
+    load_col<n>(a.TARGET + (size_t)tile * n * TILE + lane, target);
+    load_uniform<m * m>(a.WTS + n * n, Rk);
+    load_uniform<n * n>(a.WTS + n * n + m * m, QT);
+    const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+    double cost = 0.0;
+    for (int t = 0; t < a.N; ++t) {
+        double u[m];
+        load_col<m>(Up + (size_t)t * m * TILE, u);
+        cost = cost + input_cost<m>(u, Rk);
+    }
+    load_col<n>(a.X + ((size_t)tile * a.state_rows + a.N) * n * TILE + lane, x);
+    cost = cost + terminal_cost<n>(x, target, QT);
+    a.cost[tile * TILE + lane] = cost;
+}
+
+// terminal condition of backwards_pass (ilqr.py:67-70): V_x = Q_T (x_N - target); Vxx already holds Q_T
+// ------------------------------------------------------------------------------------------------
+// closed-loop rollout of one lane over steps [t0, t1) (ilqr.py:144-157), accumulating the input cost of
+// compute_cost; optionally storing the new trajectory (STORE) and the state at every segment boundary (CKPT).
+// ------------------------------------------------------------------------------------------------
+#ifndef CLOSED_LOOP_PREFETCH
+#define CLOSED_LOOP_PREFETCH 1
+#endif
+template <class S, bool STORE, bool CKPT>
+__device__ __forceinline__ double closed_loop_range(const KArgs& a, const double* Xp, const double* Up, const double* Kp,
+                                                    const double* kp, double* XOp, double* UOp, double* ckp,
+                                                    double (&x)[S::n], const double (&p)[S::np],
+                                                    const double (&Rk)[S::m * S::m], const double alpha, const int t0,
+                                                    const int t1)
+{
+    constexpr int n = S::n, m = S::m;
+    // Rows of the reference trajectory and gains for the next D steps are in flight while step t computes -- in a ring
+    // of registers when the per-step record is small (n <= 4: 10 doubles per slot), else (quadcopter: 68 doubles) only
+    // the trajectory row is one step ahead and the gains are left to the scheduler.  A slot is refilled as soon as
+    // its step's input is formed, i.e. row t+D of X is read before the STORE of row t+1 (in-place accept, D >= 1).
+    constexpr bool PREFETCH = (n + 2 * m + m * n) <= 16;
+    constexpr int D = PREFETCH ? CLOSED_LOOP_PREFETCH : 1;
+    double cost = 0.0;
+    double xb[D][n], ub[D][m], K[D][m * n], kf[D][m];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int tl = t0 + d < t1 ? t0 + d : t1 - 1;
+        load_col<n>(Xp + (size_t)tl * n * TILE, xb[d]); load_col<m>(Up + (size_t)tl * m * TILE, ub[d]);
+        if constexpr (PREFETCH) { load_col<m * n>(Kp + (size_t)tl * (m * n) * TILE, K[d]); load_col<m>(kp + (size_t)tl * m * TILE, kf[d]); }
+    }
+    int next_ck = CKPT ? a.ck : 0;
+    for (int tb = t0; tb < t1; tb += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int t = tb + d;
+            if (t >= t1) break;
+            if constexpr (!PREFETCH) {
+                load_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K[d]);
+                load_col<m>(kp + (size_t)t * m * TILE, kf[d]);
+            }
+            if constexpr (CKPT) {
+                if (t == next_ck) {                                                    // state entering segment t / ck
+                    double* c = ckp + (size_t)(t / a.ck) * n * TILE;
+#pragma unroll
+                    for (int i = 0; i < n; ++i) c[(size_t)i * TILE] = x[i];
+                    next_ck += a.ck;
+                }
+            }
+            double u[m], xn[n];
+#pragma unroll
+            for (int j = 0; j < m; ++j) {
+                const double ff = alpha * kf[d][j];                                    // :146
+                double fb = 0.0;                                                       // :147
+#pragma unroll
+                for (int i = 0; i < n; ++i) fb = __builtin_fma(K[d][j * n + i], x[i] - xb[d][i], fb);
+                u[j] = (ub[d][j] + fb) + ff;                                           // :148
+            }
+            {
+                const int tl = t + D < t1 ? t + D : t1 - 1;                            // slot d next holds step t + D
+                load_col<n>(Xp + (size_t)tl * n * TILE, xb[d]); load_col<m>(Up + (size_t)tl * m * TILE, ub[d]);
+                if constexpr (PREFETCH) { load_col<m * n>(Kp + (size_t)tl * (m * n) * TILE, K[d]); load_col<m>(kp + (size_t)tl * m * TILE, kf[d]); }
+            }
+            cost = cost + input_cost<m>(u, Rk);
+            S::f(x, u, a.dt, p, xn);                                                   // :151
+#pragma unroll
+            for (int i = 0; i < n; ++i) x[i] = xn[i];
+            if constexpr (STORE) {
+                store_col<m>(UOp + (size_t)t * m * TILE, u);                           // :154
+                store_col<n>(XOp + (size_t)(t + 1) * n * TILE, x);                     // :153
+            }
+        }
+    }
+    return cost;
+}
+
+template <class S, bool STORE, bool CKPT = false>
+__device__ __forceinline__ double closed_loop(const KArgs& a, const double* Xp, const double* Up, const double* Kp,
+                                              const double* kp, double* XOp, double* UOp, double (&x)[S::n],
+                                              const double (&p)[S::np], const double (&target)[S::n],
+                                              const double (&Rk)[S::m * S::m], const double (&QT)[S::n * S::n],
+                                              const double alpha, double* ckp = nullptr)
+{
+    double cost = closed_loop_range<S, STORE, CKPT>(a, Xp, Up, Kp, kp, XOp, UOp, ckp, x, p, Rk, alpha, 0, a.N);
+    cost = cost + terminal_cost<S::n>(x, target, QT);
+    return cost;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Line-search rollout for systems whose per-step record (x_ref, u_ref, K, k: n + 2m + mn doubles, 68 for the
+// quadcopter) is too large to prefetch in every lane's registers.  The W lanes of a problem need the SAME record, so the
+// wave loads each record once -- lane l fetches component l/G (+W, +2W, ...) of problem l%G, 64-byte runs of a tile row
+// -- and passes it through LDS (double buffered, one step ahead); every lane then reads its problem's record as
+// broadcasts.  10 vector loads per step and lane instead of 68 (W = 8), all in flight during the previous step.
+// Wave-synchronous: only this wave touches its LDS region and its LDS operations execute in order.
+// ------------------------------------------------------------------------------------------------
+template <class S, int W>
+struct Staged {
+    static constexpr int n = S::n, m = S::m, G = TILE / W;
+    static constexpr int REC = n + 2 * m + m * n, RECP = REC | 1;        // odd stride: the G records start in distinct banks
+    static constexpr int oX = 0, oU = n, oK = n + m, ok = n + m + m * n;
+    static constexpr int qX = (n + W - 1) / W, qU = (m + W - 1) / W, qK = (m * n + W - 1) / W;
+    static constexpr int WAVE_DOUBLES = 2 * G * RECP;
+    static constexpr bool use = (n + 2 * m + m * n) > 16 && W >= 8;      // smaller records are prefetched in registers
+};
+
+template <class S, int W, bool CKPT>
+__device__ __forceinline__ double closed_loop_staged(const KArgs& a, double* sw, const int lane, const int grp,
+                                                     const long long b_duty, double* ckp, const bool valid,
+                                                     double (&x)[S::n], const double (&p)[S::np],
+                                                     const double (&Rk)[S::m * S::m], const double alpha)
+{
+    using T = Staged<S, W>;
+    constexpr int n = S::n, m = S::m, G = T::G, RECP = T::RECP;
+    const int gd = lane % G, cd = lane / G;                                            // load duty: problem gd, component cd (+ W q)
+    const long long tile_d = b_duty >> 6;
+    const int pl_d = (int)(b_duty & 63);
+    const double* Xd = a.X + (size_t)tile_d * a.state_rows * n * TILE + pl_d;
+    const double* Ud = a.U + (size_t)tile_d * a.N * m * TILE + pl_d;
+    const double* Kd = a.KFB + (size_t)tile_d * a.N * (m * n) * TILE + pl_d;
+    const double* kd = a.KFF + (size_t)tile_d * a.N * m * TILE + pl_d;
+    double rX[T::qX], rU[T::qU], rK[T::qK], rk[T::qU];
+    auto fetch = [&](const int t) {
+#pragma unroll
+        for (int q = 0; q < T::qX; ++q) { const int c = cd + W * q; rX[q] = Xd[((size_t)t * n + (c < n ? c : n - 1)) * TILE]; }
+#pragma unroll
+        for (int q = 0; q < T::qU; ++q) { const int c = cd + W * q; rU[q] = Ud[((size_t)t * m + (c < m ? c : m - 1)) * TILE]; }
+#pragma unroll
+        for (int q = 0; q < T::qK; ++q) { const int c = cd + W * q; rK[q] = Kd[((size_t)t * (m * n) + (c < m * n ? c : m * n - 1)) * TILE]; }
+#pragma unroll
+        for (int q = 0; q < T::qU; ++q) { const int c = cd + W * q; rk[q] = kd[((size_t)t * m + (c < m ? c : m - 1)) * TILE]; }
+    };
+    auto stash = [&](const int t) {
+        double* d = sw + (t & 1) * (G * RECP) + gd * RECP;
+#pragma unroll
+        for (int q = 0; q < T::qX; ++q) { const int c = cd + W * q; if (c < n) d[T::oX + c] = rX[q]; }
+#pragma unroll
+        for (int q = 0; q < T::qU; ++q) { const int c = cd + W * q; if (c < m) d[T::oU + c] = rU[q]; }
+#pragma unroll
+        for (int q = 0; q < T::qK; ++q) { const int c = cd + W * q; if (c < m * n) d[T::oK + c] = rK[q]; }
+#pragma unroll
+        for (int q = 0; q < T::qU; ++q) { const int c = cd + W * q; if (c < m) d[T::ok + c] = rk[q]; }
+    };
+    fetch(0);
+    stash(0);
+    __builtin_amdgcn_wave_barrier();
+    double cost = 0.0;
+    int next_ck = CKPT ? a.ck : 0;
+    for (int t = 0; t < a.N; ++t) {
+        fetch(t + 1 < a.N ? t + 1 : t);                                                // next record, in flight during this step
+        const double* rec = sw + (t & 1) * (G * RECP) + grp * RECP;
+        if constexpr (CKPT) {
+            if (t == next_ck) {                                                        // state entering segment t / ck
+                if (valid) {
+                    double* c = ckp + (size_t)(t / a.ck) * n * TILE;
+#pragma unroll
+                    for (int i = 0; i < n; ++i) c[(size_t)i * TILE] = x[i];
+                }
+                next_ck += a.ck;
+            }
+        }
+        double u[m], xn[n], dx[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) dx[i] = x[i] - rec[T::oX + i];
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+            const double ff = alpha * rec[T::ok + j];                                  // :146
+            double fb = 0.0;                                                           // :147
+#pragma unroll
+            for (int i = 0; i < n; ++i) fb = __builtin_fma(rec[T::oK + j * n + i], dx[i], fb);
+            u[j] = (rec[T::oU + j] + fb) + ff;                                         // :148
+        }
+        cost = cost + input_cost<m>(u, Rk);
+        S::f(x, u, a.dt, p, xn);                                                       // :151
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = xn[i];
+        __builtin_amdgcn_wave_barrier();                                               // reads of this parity's other buffer are done
+        stash(t + 1);
+        __builtin_amdgcn_wave_barrier();
+    }
+    return cost;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_linesearch: ilqr.py:180-202.  W adjacent lanes evaluate W consecutive trials alpha_j of one problem
+// (64/W problems per wave); the accepted trial is the FIRST j whose Armijo ratio passes (:193), found with a
+// ballot over the lane group -- not the lowest cost.  Rounds of W trials repeat until accepted or exhausted.
+// ------------------------------------------------------------------------------------------------
+// register budget of the line search = 512 / (waves per SIMD): what each system's time step needs without spilling
+#ifndef LS_WAVES_SMALL
+#define LS_WAVES_SMALL 2
+#endif
+template <class S>
+constexpr int ls_waves_per_simd()
+{
+    return S::n > 4 ? 1 : (S::id == ILQR_DYN_ACROBOT_ID ? 2 : LS_WAVES_SMALL);   // (4 for cartpole spills 14 VGPRs and gains nothing)
+}
+template <class S, int W, bool CKPT>
+__global__ void __launch_bounds__(W == 64 ? 512 : 256, ls_waves_per_simd<S>()) k_linesearch(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m, np = S::np;
+    constexpr int G = TILE / W;
+    // logical block: neighbours (2k, 2k+1) sit 8 physical block ids apart (same XCD under round-robin dispatch)
+    const unsigned pb = blockIdx.x, nb16 = gridDim.x & ~15u;
+    const unsigned lb = pb < nb16 ? (pb & ~15u) + ((pb & 7u) << 1) + ((pb >> 3) & 1u) : pb;
+    const long long wave = ((long long)lb * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / W, al = lane % W;
+    const int r = a.ls_round;
+    long long b;
+    bool act;
+    if (r == 0) {                                            // every active problem of the (sub-)batch, in place
+        if (wave * G >= a.n_tiles * TILE) return;
+        b = a.tile0 * TILE + wave * G + grp;
+        act = a.active[b] != 0;
+    } else {                                                 // the problems round r-1 left searching, packed densely
+        const long long cnt = a.ls_count[r - 1], g = wave * G + grp;
+        if (wave * G >= cnt) return;
+        act = g < cnt;
+        b = act ? a.ls_list[(size_t)((r - 1) & 1) * a.Bpad + a.tile0 * TILE + g] : a.tile0 * TILE;
+    }
+    const long long tile = b >> 6;
+    const int pl = (int)(b & 63);
+    if (__ballot(act) == 0ull) return;
+    double x0[n], p[np], target[n], Rk[m * m], QT[n * n];
+    load_col<n>(a.INIT + (size_t)tile * n * TILE + pl, x0);
+    load_col<np>(a.PARAMS + (size_t)tile * np * TILE + pl, p);
+    load_col<n>(a.TARGET + (size_t)tile * n * TILE + pl, target);
+    load_uniform<m * m>(a.WTS + n * n, Rk);
+    load_uniform<n * n>(a.WTS + n * n + m * m, QT);
+    const double cur_cost = a.cost[b];
+    const double dg = a.dJ[((size_t)tile * 3 + 1) * TILE + pl], dh = a.dJ[((size_t)tile * 3 + 2) * TILE + pl];
+    const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + pl;
+    const double* Up = a.U + (size_t)tile * a.N * m * TILE + pl;
+    const double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + pl;
+    const double* kp = a.KFF + (size_t)tile * a.N * m * TILE + pl;
+    const int j = r * W + al;
+    const bool valid = act && j < a.n_trials;
+    double c = __builtin_nan("");
+    bool okj = false;
+    if constexpr (Staged<S, W>::use) {
+        // whole wave together (the record loads are shared); lanes without a trial compute on and are ignored
+        __shared__ double sh[(W == 64 ? 8 : 4) * Staged<S, W>::WAVE_DOUBLES];
+        double* sw = sh + (threadIdx.x >> 6) * Staged<S, W>::WAVE_DOUBLES;
+        const long long b_duty = __shfl(b, (lane % G) * W);
+        const double alpha = a.alphas[j < a.n_trials ? j : 0];
+        double x[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = x0[i];
+        double* ckp = CKPT ? a.CKPT + (size_t)b * a.n_seg * n * TILE + j : nullptr;
+        c = closed_loop_staged<S, W, CKPT>(a, sw, lane, grp, b_duty, ckp, valid, x, p, Rk, alpha);
+        c = c + terminal_cost<n>(x, target, QT);
+        const double cost_difference = cur_cost - c;                               // :191
+        const double expected = alpha * dg + (alpha * alpha) * dh;                 // :192
+        okj = valid && (cost_difference / expected) > a.armijo_thr;                // :193 (NaN -> false)
+        if (!valid) c = __builtin_nan("");
+    } else if (valid) {
+        const double alpha = a.alphas[j];
+        double x[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = x0[i];
+        double* ckp = CKPT ? a.CKPT + (size_t)b * a.n_seg * n * TILE + j : nullptr;
+        c = closed_loop<S, false, CKPT>(a, Xp, Up, Kp, kp, nullptr, nullptr, x, p, target, Rk, QT, alpha, ckp);
+        const double cost_difference = cur_cost - c;                               // :191
+        const double expected = alpha * dg + (alpha * alpha) * dh;                 // :192
+        okj = (cost_difference / expected) > a.armijo_thr;                         // :193 (NaN -> false)
+    }
+    const unsigned long long mask = __ballot(okj);
+    const unsigned long long gm = (W == 64) ? mask : ((mask >> (grp * W)) & ((1ull << (W % 64)) - 1ull));
+    const int first = gm != 0ull ? __ffsll((long long)gm) - 1 : 0;
+    const double cwin = __shfl(c, grp * W + first);
+    if (al == 0 && act) {
+        a.ls_rounds[b] += 1;
+        if (gm != 0ull) {
+            a.acc_j[b] = r * W + first;
+            a.new_cost[b] = cwin;
+        } else if ((r + 1) * W < a.n_trials) {                                     // :200-202, next round's list
+            const int slot = atomicAdd(a.ls_count + r, 1);
+            a.ls_list[(size_t)(r & 1) * a.Bpad + a.tile0 * TILE + slot] = (int)b;
+        } else {                                                                   // :204 learning rate ran out
+            a.acc_j[b] = -1;
+            a.new_cost[b] = __builtin_nan("");
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_forward: ilqr.forwards_pass (ilqr.py:137-158), one lane per problem.
+//   ACCEPT = true : the accept step of solve (:194-207): problems with acc_j >= 0 re-roll the winning alpha
+//                   in place into X/U, take new_cost as their cost; the others stop with "low learning rate".
+//   ACCEPT = false: plain forwards_pass with a per-problem alpha into XO/UO (+ its cost into new_cost).
+// ------------------------------------------------------------------------------------------------
+template <class S, bool ACCEPT>
+__global__ void __launch_bounds__(64) k_forward(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m, np = S::np;
+    const long long tile = a.tile0 + blockIdx.x;
+    const int lane = threadIdx.x;
+    const long long b = tile * TILE + lane;
+    bool run = true;
+    double alpha;
+    int accj = -1;
+    if constexpr (ACCEPT) {
+        const bool act = a.active[b] != 0;
+        accj = act ? a.acc_j[b] : -1;
+        run = act && accj >= 0;
+        alpha = a.alphas[accj >= 0 ? accj : 0];
+        if (act && accj < 0) { a.status[b] = ILQR_STATUS_LOW_LR; a.active[b] = 0; }    // :204-207
+        if (__ballot(run) == 0ull) return;
+    } else {
+        alpha = a.alpha_pp[b];
+    }
+    double x[n], p[np], target[n], Rk[m * m], QT[n * n];
+    load_col<n>(a.INIT + (size_t)tile * n * TILE + lane, x);
+    load_col<np>(a.PARAMS + (size_t)tile * np * TILE + lane, p);
+    load_col<n>(a.TARGET + (size_t)tile * n * TILE + lane, target);
+    load_uniform<m * m>(a.WTS + n * n, Rk);
+    load_uniform<n * n>(a.WTS + n * n + m * m, QT);
+    const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
+    const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+    const double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + lane;
+    const double* kp = a.KFF + (size_t)tile * a.N * m * TILE + lane;
+    double* XOp = a.XO + (size_t)tile * a.state_rows * n * TILE + lane;
+    double* UOp = a.UO + (size_t)tile * a.N * m * TILE + lane;
+    if (run) {
+        if constexpr (!ACCEPT) {
+            double x0[n];
+#pragma unroll
+            for (int i = 0; i < n; ++i) x0[i] = a.zero_first ? 0.0 : x[i];             // :138,:143 (row 0 stays zero)
+            store_col<n>(XOp, x0);
+        }
+        const double c = closed_loop<S, true>(a, Xp, Up, Kp, kp, XOp, UOp, x, p, target, Rk, QT, alpha);
+        if constexpr (ACCEPT) {
+            const double nc = a.new_cost[b];          // cost of the winning trial as the line search saw it
+            a.cost[b] = nc;                                                            // :197
+            a.accepts[b] += 1;
+            if (a.trace && a.it < a.n_iter) {
+                double* tr = a.trace + ((size_t)tile * a.n_iter + a.it) * 6 * TILE + lane;
+                tr[4 * TILE] = (double)accj; tr[5 * TILE] = nc;
+            }
+            (void)c;
+        } else {
+            a.new_cost[b] = c;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split pipeline (small batches: the horizon-sequential kernels would leave most SIMDs idle).
+//   k_accept_par : the accept step (:194-207) in parallel over (tile, segment): each lane restarts the winning
+//                  trial from the checkpoint the line search stored at its segment boundary and re-rolls ck steps
+//                  into X2/U2 (same arithmetic, same order => same bits as the trial itself).
+//   k_linearize  : parallel over (tile, block of time steps): evaluates A_t, B_t (ilqr.py:96-97) at the stored
+//                  trajectory and keeps their general entries in LIN; with COPY it first moves the accepted
+//                  trajectory X2/U2 -> X/U.
+//   k_riccati    : the horizon-sequential part of backwards_pass (:99-125) reading LIN instead of calling A(), B().
+// ------------------------------------------------------------------------------------------------
+template <class S>
+__global__ void __launch_bounds__(64) k_accept_par(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m, np = S::np;
+    const long long tile = a.tile0 + blockIdx.x / a.n_seg;
+    const int seg = (int)(blockIdx.x % a.n_seg);
+    const int lane = threadIdx.x;
+    const long long b = tile * TILE + lane;
+    const bool act = a.active[b] != 0;
+    const int accj = act ? a.acc_j[b] : -1;
+    const bool run = act && accj >= 0;
+    if (__ballot(act) == 0ull) return;
+    if (run) {
+        const double alpha = a.alphas[accj];
+        double x[n], p[np], Rk[m * m];
+        load_col<np>(a.PARAMS + (size_t)tile * np * TILE + lane, p);
+        load_uniform<m * m>(a.WTS + n * n, Rk);
+        if (seg == 0) {
+            load_col<n>(a.INIT + (size_t)tile * n * TILE + lane, x);
+        } else {
+            const double* c = a.CKPT + ((size_t)b * a.n_seg + seg) * n * TILE + accj;
+#pragma unroll
+            for (int i = 0; i < n; ++i) x[i] = c[(size_t)i * TILE];
+        }
+        const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
+        const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+        const double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + lane;
+        const double* kp = a.KFF + (size_t)tile * a.N * m * TILE + lane;
+        double* XOp = a.X2 + (size_t)tile * a.state_rows * n * TILE + lane;
+        double* UOp = a.U2 + (size_t)tile * a.N * m * TILE + lane;
+        const int t0 = seg * a.ck;
+        const int t1 = t0 + a.ck < a.N ? t0 + a.ck : a.N;
+        (void)closed_loop_range<S, true, false>(a, Xp, Up, Kp, kp, XOp, UOp, nullptr, x, p, Rk, alpha, t0, t1);
+    }
+    if (seg == 0 && act) {                                                             // per-problem bookkeeping, once
+        if (accj < 0) { a.status[b] = ILQR_STATUS_LOW_LR; a.active[b] = 0; }           // :204-207
+        else {
+            const double nc = a.new_cost[b];
+            a.cost[b] = nc;                                                            // :197
+            a.accepts[b] += 1;
+            if (a.trace && a.it < a.n_iter) {
+                double* tr = a.trace + ((size_t)tile * a.n_iter + a.it) * 6 * TILE + lane;
+                tr[4 * TILE] = (double)accj; tr[5 * TILE] = nc;
+            }
+        }
+    }
+}
+
