@@ -6,7 +6,7 @@
 //                       schedule's k_linearize / k_riccati / k_riccati_grp, k_ltvlqr (ltvlqr.py:3-28)
 //   kernels_forward.h   k_rollout (ilqr.rollout :30-47 + compute_cost :49-62), k_cost, k_linesearch (the while loop of
 //                       solve, :180-202: W trials per problem on W adjacent lanes, one launch per round, first accepted
-//                       trial by ballot), k_forward (forwards_pass :137-158 and the fused accept :194-199), k_accept_par
+//                       trial by ballot), k_forward (forwards_pass :137-158 and the fused accept :194-199), k_accept_lin
 //   kernels_util.h      k_dynamics (the lambdified f/A/B, symbolic_dynamics.py:23-25,88-90), k_pack / k_unpack
 //                       (reference layout (B,T,C) <-> tiled SoA [b/64][T][C][b%64])
 //   this file           the workspace (device-resident batch), the pass schedule of solve(), the C ABI (include/ilqr_hip.h)
@@ -90,7 +90,7 @@ struct ilqr_ws {
     hipStream_t sub_stream[4];
     hipEvent_t sub_start, sub_done[4];
     long long sub_tile0[5];
-    double *X2, *U2, *CKPT, *LIN;
+    double *XB, *CKPT, *LIN;
     int split, grp, ck, n_seg, n_lin;
     double *X, *U, *G, *KFB, *KFF, *XO, *UO, *INIT, *TARGET, *PARAMS, *WTS, *alphas, *alpha_pp, *cost, *new_cost, *dJ, *trace;
     int *active, *iters, *status, *acc_j, *ls_rounds, *accepts, *ls_list, *ls_count;
@@ -115,7 +115,7 @@ KArgs make_args(ilqr_ws* ws, int it)
     a.n_trials = ws->n_trials; a.state_rows = ws->state_rows; a.n_tiles = ws->tiles; a.tile0 = 0;
     a.dt = ws->d.dt; a.low_red = ws->d.low_expected_reduction; a.armijo_thr = ws->d.armijo_threshold;
     a.quu_reg = ws->d.quu_reg;
-    a.X2 = ws->X2; a.U2 = ws->U2; a.CKPT = ws->CKPT; a.LIN = ws->LIN; a.ck = ws->ck; a.n_seg = ws->n_seg;
+    a.XB = ws->XB; a.CKPT = ws->CKPT; a.LIN = ws->LIN; a.ck = ws->ck; a.n_seg = ws->n_seg;
     a.X = ws->X; a.U = ws->U; a.G = ws->G; a.KFB = ws->KFB; a.KFF = ws->KFF; a.XO = ws->X; a.UO = ws->U;
     a.INIT = ws->INIT; a.TARGET = ws->TARGET; a.PARAMS = ws->PARAMS; a.WTS = ws->WTS; a.alphas = ws->alphas;
     a.alpha_pp = ws->alpha_pp; a.cost = ws->cost; a.new_cost = ws->new_cost; a.dJ = ws->dJ; a.active = ws->active;
@@ -337,13 +337,11 @@ int run_pass(ilqr_ws* ws, int kid, int it, const char* name, F&& launch, int sub
     });
 }
 
-int ws_linearize(ilqr_ws* ws, bool copy, int sub = -1)
+int ws_linearize(ilqr_ws* ws, int sub = -1)
 {
     const int chunks = (ws->N + LIN_TS - 1) / LIN_TS;
     return run_pass(ws, KID_LINEARIZE, 0, "k_linearize", [&](auto S, const KArgs& a, hipStream_t st) {
-        const unsigned grid = (unsigned)(a.n_tiles * chunks);
-        if (copy) hipLaunchKernelGGL((k_linearize<decltype(S), true>), dim3(grid), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_linearize<decltype(S), false>), dim3(grid), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_linearize<decltype(S)>, dim3((unsigned)(a.n_tiles * chunks)), dim3(64), 0, st, a);
     }, sub);
 }
 int ws_riccati(ilqr_ws* ws, int it, int sub = -1)
@@ -354,10 +352,12 @@ int ws_riccati(ilqr_ws* ws, int it, int sub = -1)
         else hipLaunchKernelGGL(k_riccati<T>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
     }, sub);
 }
-int ws_accept_par(ilqr_ws* ws, int it, int sub = -1)
+int ws_accept_lin(ilqr_ws* ws, int it, int sub = -1)
 {
-    return run_pass(ws, KID_ACCEPT, it, "k_accept_par", [&](auto S, const KArgs& a, hipStream_t st) {
-        hipLaunchKernelGGL(k_accept_par<decltype(S)>, dim3((unsigned)(a.n_tiles * ws->n_seg)), dim3(64), 0, st, a);
+    return run_pass(ws, KID_ACCEPT, it, "k_accept_lin", [&](auto S, const KArgs& a, hipStream_t st) {
+        const dim3 grid((unsigned)(a.n_tiles * ws->n_seg));
+        hipLaunchKernelGGL(k_save_boundaries, grid, dim3(64), 0, st, a, (int)decltype(S)::n);
+        hipLaunchKernelGGL(k_accept_lin<decltype(S)>, grid, dim3(64), 0, st, a);
     }, sub);
 }
 int ws_rollout(ilqr_ws* ws, int sub = -1)
@@ -419,12 +419,11 @@ int ws_solve_chain(ilqr_ws* ws, int sub)
     int rc;
     if ((rc = ws_rollout(ws, sub))) return rc;                       // :162-164
     if (ws->split) {
-        if ((rc = ws_linearize(ws, false, sub))) return rc;          // A_t, B_t of the initial trajectory (:96-97)
+        if ((rc = ws_linearize(ws, sub))) return rc;                 // A_t, B_t of the initial trajectory (:96-97)
         for (int it = 0; it < ws->d.n_iterations; ++it) {            // :170
             if ((rc = ws_riccati(ws, it, sub))) return rc;           // :99-135, :173-179
             if ((rc = ws_linesearch(ws, sub))) return rc;            // :180-202 (+ checkpoints)
-            if ((rc = ws_accept_par(ws, it, sub))) return rc;        // :194-207, segments in parallel
-            if ((rc = ws_linearize(ws, true, sub))) return rc;       // accepted trajectory back + A_t, B_t for the next pass
+            if ((rc = ws_accept_lin(ws, it, sub))) return rc;        // :194-207 in place, segments in parallel, + A_t, B_t
         }
         return 0;
     }
@@ -602,7 +601,7 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
         {(void**)&ws->ls_rounds, Bp * 4}, {(void**)&ws->accepts, Bp * 4}, {(void**)&ws->ls_list, 2 * Bp * 4},
         {(void**)&ws->ls_count, 5 * MAX_TRIALS * 4},
         {(void**)&ws->trace, ws->want_trace ? Bp * (size_t)d->n_iterations * 6 * 8 : 0},
-        {(void**)&ws->X2, ws->split ? Bp * (N + 1) * n * 8 : 0}, {(void**)&ws->U2, ws->split ? Bp * N * m * 8 : 0},
+        {(void**)&ws->XB, ws->split ? Bp * (size_t)ws->n_seg * n * 8 : 0},
         {(void**)&ws->CKPT, ws->split ? Bp * (size_t)ws->n_seg * n * TILE * 8 : 0},
         {(void**)&ws->LIN, ws->split ? Bp * N * (size_t)ws->n_lin * 8 : 0},
     };
@@ -654,7 +653,7 @@ int ilqr_ws_destroy(ilqr_ws* ws)
     (void)hipSetDevice(ws->d.device);
     if (ws->stream) (void)hipStreamSynchronize(ws->stream);
     for (auto& ev : ws->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    void* ptrs[] = {ws->X2, ws->U2, ws->CKPT, ws->LIN, ws->X, ws->U, ws->G, ws->KFB, ws->KFF, ws->XO, ws->UO, ws->INIT, ws->TARGET, ws->PARAMS, ws->WTS, ws->alphas,
+    void* ptrs[] = {ws->XB, ws->CKPT, ws->LIN, ws->X, ws->U, ws->G, ws->KFB, ws->KFF, ws->XO, ws->UO, ws->INIT, ws->TARGET, ws->PARAMS, ws->WTS, ws->alphas,
                     ws->alpha_pp, ws->cost, ws->new_cost, ws->dJ, ws->trace, ws->active, ws->iters, ws->status, ws->acc_j,
                     ws->ls_rounds, ws->accepts, ws->ls_list, ws->ls_count, ws->staging};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -736,7 +735,7 @@ int ilqr_ws_cost(ilqr_ws* ws)
 int ilqr_ws_backward(ilqr_ws* ws, int32_t iteration)
 {
     if (ws && ws->split) {
-        int rc = ws_linearize(ws, false);
+        int rc = ws_linearize(ws);
         return rc ? rc : ws_riccati(ws, iteration);
     }
     return ws_backward(ws, iteration);

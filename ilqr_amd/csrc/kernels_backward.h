@@ -104,7 +104,19 @@ struct Lin {
 
 constexpr int LIN_TS = 8;   // time steps per wave in k_linearize
 
-template <class S, bool COPY>
+// the general entries of A_t, B_t, in pattern order, into the step's LIN record
+template <class S>
+__device__ __forceinline__ void store_lin(double* l, const double (&A)[S::n * S::n], const double (&Bm)[S::n * S::m])
+{
+    constexpr int n = S::n, m = S::m;
+    int e = 0;
+#pragma unroll
+    for (int i = 0; i < n * n; ++i) if (S::a_kind(i) == 'x') { l[(size_t)e * TILE] = A[i]; ++e; }
+#pragma unroll
+    for (int i = 0; i < n * m; ++i) if (S::b_kind(i) == 'x') { l[(size_t)e * TILE] = Bm[i]; ++e; }
+}
+
+template <class S>
 __global__ void __launch_bounds__(64) k_linearize(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
@@ -113,44 +125,24 @@ __global__ void __launch_bounds__(64) k_linearize(const KArgs a)
     const int chunk = (int)(blockIdx.x % chunks);
     const int lane = threadIdx.x;
     const long long b = tile * TILE + lane;
-    const bool act = a.active[b] != 0;
-    const bool run = COPY ? (act && a.acc_j[b] >= 0) : act;
+    const bool run = a.active[b] != 0;
     if (__ballot(run) == 0ull) return;
     if (!run) return;
     double p[np];
     load_col<np>(a.PARAMS + (size_t)tile * np * TILE + lane, p);
-    double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
-    double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
-    const double* X2p = a.X2 + (size_t)tile * a.state_rows * n * TILE + lane;
-    const double* U2p = a.U2 + (size_t)tile * a.N * m * TILE + lane;
+    const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
+    const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
     double* Lp = a.LIN + (size_t)tile * a.N * Lin<S>::n_lin * TILE + lane;
     const int t0 = chunk * LIN_TS;
     const int t1 = t0 + LIN_TS < a.N ? t0 + LIN_TS : a.N;
     for (int t = t0; t < t1; ++t) {
         double x[n], u[m];
-        if constexpr (COPY) {
-            if (t == 0) load_col<n>(Xp, x);                 // row 0 never changes (zero or init_state)
-            else { load_col<n>(X2p + (size_t)t * n * TILE, x); store_col<n>(Xp + (size_t)t * n * TILE, x); }
-            load_col<m>(U2p + (size_t)t * m * TILE, u);
-            store_col<m>(Up + (size_t)t * m * TILE, u);
-            if (t == a.N - 1) {
-                double xN[n];
-                load_col<n>(X2p + (size_t)a.N * n * TILE, xN);
-                store_col<n>(Xp + (size_t)a.N * n * TILE, xN);
-            }
-        } else {
-            load_col<n>(Xp + (size_t)t * n * TILE, x);
-            load_col<m>(Up + (size_t)t * m * TILE, u);
-        }
+        load_col<n>(Xp + (size_t)t * n * TILE, x);
+        load_col<m>(Up + (size_t)t * m * TILE, u);
         double A[n * n], Bm[n * m];
         S::A(x, u, a.dt, p, A);                                                        // :96
         S::B(x, u, a.dt, p, Bm);                                                       // :97
-        double* l = Lp + (size_t)t * Lin<S>::n_lin * TILE;
-        int e = 0;
-#pragma unroll
-        for (int i = 0; i < n * n; ++i) if (S::a_kind(i) == 'x') { l[(size_t)e * TILE] = A[i]; ++e; }
-#pragma unroll
-        for (int i = 0; i < n * m; ++i) if (S::b_kind(i) == 'x') { l[(size_t)e * TILE] = Bm[i]; ++e; }
+        store_lin<S>(Lp + (size_t)t * Lin<S>::n_lin * TILE, A, Bm);
     }
 }
 

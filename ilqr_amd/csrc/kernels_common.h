@@ -55,8 +55,7 @@ struct KArgs {
     const double* G;       // [tile][N][m][64] initial guess (read by k_rollout only)
     double* KFB;           // [tile][N][m*n][64]
     double* KFF;           // [tile][N][m][64]
-    double* X2;            // split pipeline: accepted trajectory before it is copied back, same layout as X / U
-    double* U2;
+    double* XB;            // split pipeline: [tile][segment][n][64] reference-state row at every segment boundary, saved before the in-place accept
     double* CKPT;          // [problem][segment][n][64 trial slots] line-search checkpoints
     double* LIN;           // [tile][N][nA_x + nB_x][64] general entries of A_t, B_t
     int ck;                // checkpoint interval (time steps per segment)

@@ -72,13 +72,15 @@ __global__ void __launch_bounds__(64) k_cost(const KArgs a)
 #ifndef CLOSED_LOOP_PREFETCH
 #define CLOSED_LOOP_PREFETCH 1
 #endif
-template <class S, bool STORE, bool CKPT>
+template <class S, bool STORE, bool CKPT, bool LINOUT = false>
 __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double* Xp, const double* Up, const double* Kp,
                                                     const double* kp, double* XOp, double* UOp, double* ckp,
                                                     double (&x)[S::n], const double (&p)[S::np],
                                                     const double (&Rk)[S::m * S::m], const double alpha, const int t0,
-                                                    const int t1)
+                                                    const int t1, const double* Xfirst = nullptr, double* Lp = nullptr)
 {
+    // Xfirst: where the reference-state row of step t0 is kept when X itself is being overwritten by a neighbour
+    // (k_accept_lin).  LINOUT: also evaluate A_t, B_t at the new (x_t, u_t) and store them for the next backward pass.
     constexpr int n = S::n, m = S::m;
     // Rows of the reference trajectory and gains for the next D steps are in flight while step t computes -- in a ring
     // of registers when the per-step record is small (n <= 4: 10 doubles per slot), else (quadcopter: 68 doubles) only
@@ -91,7 +93,8 @@ __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         const int tl = t0 + d < t1 ? t0 + d : t1 - 1;
-        load_col<n>(Xp + (size_t)tl * n * TILE, xb[d]); load_col<m>(Up + (size_t)tl * m * TILE, ub[d]);
+        load_col<n>(Xfirst != nullptr && tl == t0 ? Xfirst : Xp + (size_t)tl * n * TILE, xb[d]);
+        load_col<m>(Up + (size_t)tl * m * TILE, ub[d]);
         if constexpr (PREFETCH) { load_col<m * n>(Kp + (size_t)tl * (m * n) * TILE, K[d]); load_col<m>(kp + (size_t)tl * m * TILE, kf[d]); }
     }
     int next_ck = CKPT ? a.ck : 0;
@@ -120,6 +123,14 @@ __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double
 #pragma unroll
                 for (int i = 0; i < n; ++i) fb = __builtin_fma(K[d][j * n + i], x[i] - xb[d][i], fb);
                 u[j] = (ub[d][j] + fb) + ff;                                           // :148
+            }
+            if constexpr (LINOUT) {                                                    // :96-97 for the next backward pass
+                double xl[n], A[n * n], Bm[n * m];
+#pragma unroll
+                for (int i = 0; i < n; ++i) xl[i] = t == 0 ? xb[d][i] : x[i];          // row 0 as stored (quirk Q1), else x_t
+                S::A(xl, u, a.dt, p, A);
+                S::B(xl, u, a.dt, p, Bm);
+                store_lin<S>(Lp + (size_t)t * Lin<S>::n_lin * TILE, A, Bm);
             }
             {
                 const int tl = t + D < t1 ? t + D : t1 - 1;                            // slot d next holds step t + D
@@ -412,16 +423,17 @@ __global__ void __launch_bounds__(64) k_forward(const KArgs a)
 
 // ------------------------------------------------------------------------------------------------
 // Split pipeline (small batches: the horizon-sequential kernels would leave most SIMDs idle).
-//   k_accept_par : the accept step (:194-207) in parallel over (tile, segment): each lane restarts the winning
+//   k_accept_lin : the accept step (:194-207) in parallel over (tile, segment): each lane restarts the winning
 //                  trial from the checkpoint the line search stored at its segment boundary and re-rolls ck steps
-//                  into X2/U2 (same arithmetic, same order => same bits as the trial itself).
-//   k_linearize  : parallel over (tile, block of time steps): evaluates A_t, B_t (ilqr.py:96-97) at the stored
-//                  trajectory and keeps their general entries in LIN; with COPY it first moves the accepted
-//                  trajectory X2/U2 -> X/U.
+//                  IN PLACE into X/U (same arithmetic, same order => same bits as the trial itself), and evaluates
+//                  A_t, B_t (ilqr.py:96-97) at the new (x_t, u_t) into LIN on the way.  The only row two segments
+//                  share is the boundary row (last state of one = reference state of the next one's first step):
+//                  k_save_boundaries copies those rows to XB beforehand.
+//   k_linearize  : parallel over (tile, block of time steps): A_t, B_t of the initial rollout into LIN.
 //   k_riccati    : the horizon-sequential part of backwards_pass (:99-125) reading LIN instead of calling A(), B().
 // ------------------------------------------------------------------------------------------------
 template <class S>
-__global__ void __launch_bounds__(64) k_accept_par(const KArgs a)
+__global__ void __launch_bounds__(64) k_accept_lin(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
     const long long tile = a.tile0 + blockIdx.x / a.n_seg;
@@ -448,11 +460,13 @@ __global__ void __launch_bounds__(64) k_accept_par(const KArgs a)
         const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
         const double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + lane;
         const double* kp = a.KFF + (size_t)tile * a.N * m * TILE + lane;
-        double* XOp = a.X2 + (size_t)tile * a.state_rows * n * TILE + lane;
-        double* UOp = a.U2 + (size_t)tile * a.N * m * TILE + lane;
+        double* XOp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
+        double* UOp = a.U + (size_t)tile * a.N * m * TILE + lane;
+        double* Lp = a.LIN + (size_t)tile * a.N * Lin<S>::n_lin * TILE + lane;
+        const double* Xfirst = seg > 0 ? a.XB + ((size_t)(tile * a.n_seg + seg) * n) * TILE + lane : nullptr;
         const int t0 = seg * a.ck;
         const int t1 = t0 + a.ck < a.N ? t0 + a.ck : a.N;
-        (void)closed_loop_range<S, true, false>(a, Xp, Up, Kp, kp, XOp, UOp, nullptr, x, p, Rk, alpha, t0, t1);
+        (void)closed_loop_range<S, true, false, true>(a, Xp, Up, Kp, kp, XOp, UOp, nullptr, x, p, Rk, alpha, t0, t1, Xfirst, Lp);
     }
     if (seg == 0 && act) {                                                             // per-problem bookkeeping, once
         if (accj < 0) { a.status[b] = ILQR_STATUS_LOW_LR; a.active[b] = 0; }           // :204-207
@@ -466,5 +480,17 @@ __global__ void __launch_bounds__(64) k_accept_par(const KArgs a)
             }
         }
     }
+}
+
+// reference-state rows at the segment boundaries, before k_accept_lin overwrites X in place (system independent)
+__global__ void __launch_bounds__(64) k_save_boundaries(const KArgs a, const int n)
+{
+    const long long tile = a.tile0 + blockIdx.x / a.n_seg;
+    const int seg = (int)(blockIdx.x % a.n_seg);
+    const int lane = threadIdx.x;
+    if (seg == 0) return;
+    const double* src = a.X + ((size_t)tile * a.state_rows + (size_t)seg * a.ck) * n * TILE + lane;
+    double* dst = a.XB + ((size_t)(tile * a.n_seg + seg) * n) * TILE + lane;
+    for (int i = 0; i < n; ++i) dst[(size_t)i * TILE] = src[(size_t)i * TILE];
 }
 
