@@ -423,7 +423,8 @@ int ws_solve_chain(ilqr_ws* ws, int sub)
         for (int it = 0; it < ws->d.n_iterations; ++it) {            // :170
             if ((rc = ws_riccati(ws, it, sub))) return rc;           // :99-135, :173-179
             if ((rc = ws_linesearch(ws, sub))) return rc;            // :180-202 (+ checkpoints)
-            if ((rc = ws_accept_lin(ws, it, sub))) return rc;        // :194-207 in place, segments in parallel, + A_t, B_t
+            if ((rc = ws_accept_lin(ws, it, sub))) return rc;        // :194-207 in place, segments in parallel
+            if (!ACCEPT_FUSES_LINEARIZE && (rc = ws_linearize(ws, sub))) return rc;   // A_t, B_t for the next pass
         }
         return 0;
     }

@@ -69,6 +69,15 @@ __global__ void __launch_bounds__(64) k_cost(const KArgs a)
 // closed-loop rollout of one lane over steps [t0, t1) (ilqr.py:144-157), accumulating the input cost of
 // compute_cost; optionally storing the new trajectory (STORE) and the state at every segment boundary (CKPT).
 // ------------------------------------------------------------------------------------------------
+// 1: k_accept_lin also evaluates A_t, B_t (one pass over the trajectory); 0: k_linearize does it afterwards.  Measured on
+// the headline config: fused 0.81 ms (200 B per problem and step), separate 0.32 + 0.53 ms (240 B): either way the pair
+// moves ~3.4 TB/s of mixed reads and writes; the old X2/U2 copy-back schedule took 0.39 + 0.70 ms.
+#ifndef ACCEPT_FUSES_LINEARIZE
+#define ACCEPT_FUSES_LINEARIZE 1
+#endif
+#ifndef ACCEPT_PREFETCH
+#define ACCEPT_PREFETCH 1
+#endif
 #ifndef CLOSED_LOOP_PREFETCH
 #define CLOSED_LOOP_PREFETCH 1
 #endif
@@ -87,7 +96,7 @@ __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double
     // the trajectory row is one step ahead and the gains are left to the scheduler.  A slot is refilled as soon as
     // its step's input is formed, i.e. row t+D of X is read before the STORE of row t+1 (in-place accept, D >= 1).
     constexpr bool PREFETCH = (n + 2 * m + m * n) <= 16;
-    constexpr int D = PREFETCH ? CLOSED_LOOP_PREFETCH : 1;
+    constexpr int D = PREFETCH ? (LINOUT ? ACCEPT_PREFETCH : CLOSED_LOOP_PREFETCH) : 1;   // the accept streams: deeper
     double cost = 0.0;
     double xb[D][n], ub[D][m], K[D][m * n], kf[D][m];
 #pragma unroll
@@ -466,7 +475,7 @@ __global__ void __launch_bounds__(64) k_accept_lin(const KArgs a)
         const double* Xfirst = seg > 0 ? a.XB + ((size_t)(tile * a.n_seg + seg) * n) * TILE + lane : nullptr;
         const int t0 = seg * a.ck;
         const int t1 = t0 + a.ck < a.N ? t0 + a.ck : a.N;
-        (void)closed_loop_range<S, true, false, true>(a, Xp, Up, Kp, kp, XOp, UOp, nullptr, x, p, Rk, alpha, t0, t1, Xfirst, Lp);
+        (void)closed_loop_range<S, true, false, ACCEPT_FUSES_LINEARIZE != 0>(a, Xp, Up, Kp, kp, XOp, UOp, nullptr, x, p, Rk, alpha, t0, t1, Xfirst, Lp);
     }
     if (seg == 0 && act) {                                                             // per-problem bookkeeping, once
         if (accj < 0) { a.status[b] = ILQR_STATUS_LOW_LR; a.active[b] = 0; }           // :204-207
