@@ -164,7 +164,7 @@ int ilqr_ws_solve(ilqr_ws* ws);            /* ilqr.py:159-211: reset, rollout, n
 int ilqr_ws_ltvlqr(ilqr_ws* ws);           /* ltvlqr.py:3-28 on STATES/INPUTS -> KFB */
 int ilqr_ws_sync(ilqr_ws* ws);
 /* kernel timing with HIP events on the workspace stream.  kernel ids: 0 rollout, 1 backward, 2 linesearch, 3 accept,
- * 4 ltvlqr, 5 forward, 6 cost, 7 linearize.  In the split pipeline backward = k_riccati, accept = k_accept_par.
+ * 4 ltvlqr, 5 forward, 6 cost, 7 linearize.  In the split pipeline backward = k_riccati, accept = k_save_boundaries + k_accept_lin (which also writes A_t, B_t); linesearch = all rounds of a pass.
  * ms[i] = summed duration, launches[i] = count since the last enable. */
 int ilqr_ws_profile(ilqr_ws* ws, int32_t enable);
 int ilqr_ws_profile_read(ilqr_ws* ws, double* ms /*8*/, int64_t* launches /*8*/);
