@@ -12,7 +12,7 @@ t0 = time.time()
 if which == 'c3':
     csv, g = np.load(G + '/acrobot_csv.npz'), np.load(G + '/acrobot_ltvlqr.npz')
     B, N = int(65536 * scale), 3000
-    ws = ilqr_amd.Workspace('acrobot', N, B, 1e-3)
+    ws = ilqr_amd.Workspace('acrobot', N, B, 1e-3, zero_first_state=False)
     ws.set_weights(g['Qk'], g['Rk'], g['QT']); ws.upload(_lib.F_PARAMS, g['params'])
     rng = np.random.default_rng(1)
     st = np.broadcast_to(csv['states'], (B, N + 1, 4)) + 1e-2 * rng.standard_normal((B, N + 1, 4)); st[0] = csv['states']
@@ -22,6 +22,14 @@ if which == 'c3':
     print('upload %.1fs' % (time.time() - t0))
     for _ in range(2):
         t0 = time.time(); ws.ltvlqr(); ws.sync(); print('ltvlqr %.1f ms' % (1e3 * (time.time() - t0)))
+    # the consumer of the gain schedule -- closed-loop tracking from perturbed initial states, K stays in HBM
+    init = np.array([-np.pi / 2, 0, 0, 0]) + rng.uniform(-np.pi / 8, np.pi / 8, (B, 4)) * np.array([1, 1, 0.2, 0.2])
+    ws.upload(_lib.F_INIT, init); ws.upload(_lib.F_ALPHA, np.zeros(B)); ws.sync()
+    for _ in range(2):
+        t0 = time.time(); ws.forward(with_cost=False); ws.sync(); print('tracking rollout %.1f ms' % (1e3 * (time.time() - t0)))
+    xs = ws.download(_lib.F_STATES_OUT)
+    err = np.linalg.norm(xs[:, -1, :2] - st[:, -1, :2], axis=1)
+    print('tracking: final angle error median %.3g, p99 %.3g rad; finite %s' % (np.median(err), np.quantile(err, 0.99), np.isfinite(xs).all()))
     K = ws.download(_lib.F_KFB)
     print('K0 rel err vs golden', np.max(np.abs(K[0] - g['K'])) / np.max(np.abs(g['K'])), 'finite', np.isfinite(K).all())
 else:
