@@ -39,7 +39,7 @@ else:
     N = g['guess'].shape[0]
     n = g['init'].shape[0]
     rng = np.random.default_rng(2 if which == 'c4' else 3)
-    W = 8 if which == 'c4' else 0
+    W = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     ws = ilqr_amd.Workspace(sysname, N, B, float(g['dt']), want_trace=True, n_iterations=10, n_alpha_parallel=W,
                             target_batched=(which == 'c5'))
     print(ws.info())
