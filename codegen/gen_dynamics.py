@@ -176,6 +176,9 @@ def _function(model, what, mat):
     els = em.elements()
     lines = ['ILQR_DYN_FN void ilqr_dyn_%s_%s(const double* x, const double* u, const double dt, '
              'const double* p, double* out)' % (model.name, what), '{']
+    if what == 'f':
+        # the includer may allow fused multiply-adds inside f (and only there): ILQR_DYN_F_PROLOGUE, first in the body
+        lines.append('    ILQR_DYN_F_PROLOGUE')
     lines.append('    (void)x; (void)u; (void)dt; (void)p;')
     # f only: sin/cos of (a + b) where a and b already have their pair -> angle addition (ILQR_DYN_SINCOS_SUM).  In f
     # every trig value is scaled by dt before it meets the state, so the ~2e-16 absolute error of the sum formula is far
@@ -231,7 +234,7 @@ def generate(name):
                  ' * Reference: /root/reference/python/symbolic_dynamics.py:23-25,88-90 (lambdify call sites).\n'
                  ' * Row-major: f out[n], A out[n*n] (A[i][j] = out[i*n+j]), B out[n*m].\n'
                  ' * The includer defines ILQR_DYN_FN, ILQR_DYN_CONST, ILQR_DYN_SINCOS(x, s, c), ILQR_DYN_SINCOS_SLOW(x, s, c),\n'
-                 ' * ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c), ILQR_DYN_TRIG_BIG(x), ILQR_DYN_TAN(x), ILQR_DYN_TAN_SC(x, s, c), ILQR_DYN_RCP(d), ILQR_DYN_DIV(a, d, rd) and must compile\n'
+                 ' * ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c), ILQR_DYN_TRIG_BIG(x), ILQR_DYN_TAN(x), ILQR_DYN_TAN_SC(x, s, c), ILQR_DYN_RCP(d), ILQR_DYN_DIV(a, d, rd), ILQR_DYN_F_PROLOGUE and must compile\n'
                  ' * with -ffp-contract=off. */'
                  % (name, name))
     parts.append('#ifndef ILQR_DYN_%s_H\n#define ILQR_DYN_%s_H' % (up, up))

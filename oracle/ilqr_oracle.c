@@ -33,6 +33,7 @@
 /* numpy's sin/cos are glibc's: one libm call each, as the lambdified callables make */
 #define ILQR_DYN_SINCOS(x, s, c) do { (s) = sin(x); (c) = cos(x); } while (0)
 #define ILQR_DYN_SINCOS_SLOW(x, s, c) do { } while (0)
+#define ILQR_DYN_F_PROLOGUE              /* the reference: every operation rounded separately */
 #define ILQR_DYN_TAN_SC(x, s, c) tan(x)   /* the reference: numpy tan */
 #define ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c) do { (s) = sin((a) + (b)); (c) = cos((a) + (b)); } while (0)   /* the reference: numpy sin/cos of the rounded sum */
 #define ILQR_DYN_TRIG_BIG(x) 0
