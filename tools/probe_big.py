@@ -26,4 +26,8 @@ for _ in range(2):
     print('%s B=%d N=%d %d iterations: %.1f ms -> %.0f solves/s' % (system, B, N, n_it, 1e3 * dt, B / dt))
 print({k: (round(v[0] / max(v[1], 1), 2), v[1]) for k, v in ws.profile_read().items() if v[1]})
 st = ws.download(_lib.F_STATUS); it = ws.download(_lib.F_ITERS)
+info = ws.info(); rounds = ws.download(_lib.F_LS_ROUNDS); tr = ws.download(_lib.F_TRACE)
+ran = np.isfinite(tr[:, :, 1]).sum()
+need = np.where(tr[:, :, 4] >= 0, tr[:, :, 4] + 1, info['n_trials'])[np.isfinite(tr[:, :, 1])].sum()
+print('trials evaluated per search %.1f, needed by the sequential search %.1f' % (rounds.sum() * info['n_alpha_parallel'] / ran, need / ran))
 print('status counts', np.bincount(st, minlength=4), 'mean iterations', it.mean())
