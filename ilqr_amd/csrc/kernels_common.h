@@ -76,7 +76,9 @@ struct KArgs {
     int* status;
     int* acc_j;
     int* ls_rounds;
-    int ls_round;          // line search: round r evaluates trials [r*W, r*W + W)
+    int ls_round;          // line search: round r evaluates trials [ls_j0, ls_j0 + W) (W is the launched kernel's width)
+    int ls_j0;
+    int ls_last;           // no round follows: a search that fails here has run out of learning rate
     int* ls_list;          // [2][Bpad] problems still searching after a round (ping-pong by round parity)
     int* ls_count;         // [MAX_TRIALS] length of the list each round leaves (zeroed before round 0)
     int* accepts;

@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(W == 64 ? 512 : 256, ls_waves_per_simd<S>()) k
     const double* Up = a.U + (size_t)tile * a.N * m * TILE + pl;
     const double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + pl;
     const double* kp = a.KFF + (size_t)tile * a.N * m * TILE + pl;
-    const int j = r * W + al;
+    const int j = a.ls_j0 + al;
     const bool valid = act && j < a.n_trials;
     double c = __builtin_nan("");
     bool okj = false;
@@ -357,9 +357,9 @@ __global__ void __launch_bounds__(W == 64 ? 512 : 256, ls_waves_per_simd<S>()) k
     if (al == 0 && act) {
         a.ls_rounds[b] += 1;
         if (gm != 0ull) {
-            a.acc_j[b] = r * W + first;
+            a.acc_j[b] = a.ls_j0 + first;
             a.new_cost[b] = cwin;
-        } else if ((r + 1) * W < a.n_trials) {                                     // :200-202, next round's list
+        } else if (!a.ls_last) {                                                   // :200-202, next round's list
             const int slot = atomicAdd(a.ls_count + r, 1);
             a.ls_list[(size_t)(r & 1) * a.Bpad + a.tile0 * TILE + slot] = (int)b;
         } else {                                                                   // :204 learning rate ran out

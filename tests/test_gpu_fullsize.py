@@ -186,3 +186,27 @@ def test_c5_quadcopter_32768(amd, oracle):
     trace, status, iters, cost = check_properties(amd, ws, 'quadcopter', g, init, sample)
     assert cost[9] == cost[20000]
     compare_sample_with_oracle(oracle, 'quadcopter', g, init, guess, target, ws, [0, 9, 32767], 10)
+
+
+@pytest.mark.parametrize('system,B,N', [('pendulum', 65536, 300), ('acrobot', 32768, 200)])
+def test_widening_round_schedule_changes_nothing(amd, system, B, N):
+    """auto width on a batch that fills the chip several times over runs rounds of 4, 4, 8, 16, 16, 16 trials instead of
+    fixed-width rounds: a scheduling choice, bit-identical to 59 trials evaluated 32 at a time"""
+    from ilqr_amd import _lib
+    g = golden(system + '_batch')
+    rng = np.random.default_rng(17)
+    n, m = g['init'].shape[1], g['guess'].shape[2]
+    blk = 512
+    init = np.tile(g['init'][0] + rng.uniform(-0.2, 0.2, (blk, n)), (B // blk, 1))
+    guess = np.resize(g['guess'][0], (N, m))[None] + 0.05 * rng.standard_normal((blk, N, m))
+    guess = np.ascontiguousarray(np.broadcast_to(guess[None], (B // blk, blk, N, m)).reshape(B, N, m))
+    outs = []
+    for W in (0, 32):
+        ws = solve_ws(amd, system, g, init, guess, g['target'], 4, W=W)
+        outs.append([ws.download(f) for f in (_lib.F_COST, _lib.F_STATUS, _lib.F_ITERS, _lib.F_TRACE, _lib.F_ACCEPTS)]
+                    + [ws.download(_lib.F_STATES)[::997], ws.download(_lib.F_KFB)[::997]])
+        ws.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+    if system == 'acrobot':                                  # some searches went through every round (none accepted)
+        assert (outs[0][3][:, :, 4] == -1).any()

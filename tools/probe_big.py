@@ -29,5 +29,5 @@ st = ws.download(_lib.F_STATUS); it = ws.download(_lib.F_ITERS)
 info = ws.info(); rounds = ws.download(_lib.F_LS_ROUNDS); tr = ws.download(_lib.F_TRACE)
 ran = np.isfinite(tr[:, :, 1]).sum()
 need = np.where(tr[:, :, 4] >= 0, tr[:, :, 4] + 1, info['n_trials'])[np.isfinite(tr[:, :, 1])].sum()
-print('trials evaluated per search %.1f, needed by the sequential search %.1f' % (rounds.sum() * info['n_alpha_parallel'] / ran, need / ran))
+print('rounds per search %.2f, trials needed by the sequential search %.1f' % (rounds.sum() / ran, need / ran))
 print('status counts', np.bincount(st, minlength=4), 'mean iterations', it.mean())
