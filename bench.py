@@ -250,6 +250,10 @@ def main():
                                'gpu_vs_cpu_cost_max_rel_diff': float(np.max(np.abs(cost[:sample] - r['cost']) / np.abs(r['cost']))),
                                'gpu_vs_cpu_cost_frac_within_1e-8': float(np.mean(np.abs(cost[:sample] - r['cost']) <= 1e-8 * np.abs(r['cost']))),
                                'gpu_vs_cpu_same_exit_status_frac': float(np.mean(status[:sample] == r['status']))}
+        one = min(64, B)                                  # the same code on ONE core (SURVEY 8d asks for both figures)
+        v1, secs1, _ = cpu_baseline(cfg, args.iterations, one, 1)
+        out['cpu_baseline']['single_core'] = {'value': round(v1, 3), 'unit': 'solves/s', 'cores': 1,
+                                              'sample': 'first %d problems, %.1f s' % (one, secs1)}
     json_out.write(json.dumps(out) + '\n')
     json_out.flush()
     if dist is not None:
