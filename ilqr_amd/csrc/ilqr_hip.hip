@@ -349,10 +349,12 @@ int run_pass(ilqr_ws* ws, int kid, int it, const char* name, F&& launch, int sub
     });
 }
 
-int ws_linearize(ilqr_ws* ws, int sub = -1)
+int ws_linearize(ilqr_ws* ws, int sub = -1, bool all_problems = false)
 {
     const int chunks = (ws->N + LIN_TS - 1) / LIN_TS;
-    return run_pass(ws, KID_LINEARIZE, 0, "k_linearize", [&](auto S, const KArgs& a, hipStream_t st) {
+    return run_pass(ws, KID_LINEARIZE, 0, "k_linearize", [&](auto S, const KArgs& a0, hipStream_t st) {
+        KArgs a = a0;
+        a.all_problems = all_problems ? 1 : 0;
         hipLaunchKernelGGL(k_linearize<decltype(S)>, dim3((unsigned)(a.n_tiles * chunks)), dim3(64), 0, st, a);
     }, sub);
 }
@@ -800,6 +802,14 @@ int ilqr_ws_forward(ilqr_ws* ws, int32_t with_cost)
 }
 int ilqr_ws_ltvlqr(ilqr_ws* ws)
 {
+    if (ws && ws->grp && ws->LIN) {        // n > 4: P does not fit one lane -- Jacobians in parallel, then the lane-group recursion
+        int rc = ws_linearize(ws, -1, true);
+        if (rc) return rc;
+        return run_pass(ws, KID_LTVLQR, 0, "k_riccati_grp<ltv>", [&](auto S, const KArgs& a, hipStream_t st) {
+            using T = decltype(S);
+            hipLaunchKernelGGL((k_riccati_grp<T, true>), dim3((unsigned)(a.n_tiles * Grp<T>::GL)), dim3(64), 0, st, a);
+        });
+    }
     return run_pass(ws, KID_LTVLQR, 0, "k_ltvlqr", [&](auto S, const KArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(k_ltvlqr<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
     });

@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(64) k_linearize(const KArgs a)
     const int chunk = (int)(blockIdx.x % chunks);
     const int lane = threadIdx.x;
     const long long b = tile * TILE + lane;
-    const bool run = a.active[b] != 0;
+    const bool run = a.all_problems != 0 || a.active[b] != 0;
     if (__ballot(run) == 0ull) return;
     if (!run) return;
     double p[np];
@@ -287,7 +287,9 @@ __device__ __forceinline__ void static_for(F&& f)
     }
 }
 
-template <class S>
+// LTV = true: the ltvlqr recursion (ltvlqr.py:14-27) on the same lane mapping -- no V_x, k or expected reductions, the
+// value update is P = (Q + A'PA) - (A'PB) G^-1 (B'PA) with A'PB formed from the rows of A'P as the reference does.
+template <class S, bool LTV = false>
 __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KArgs a)
 {
     using G = Grp<S>;
@@ -302,7 +304,7 @@ __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KAr
     const long long b = a.tile0 * TILE + (long long)lb * P + grp;
     const long long tile = b >> 6;
     const int pl = (int)(b & 63);
-    const bool act = a.active[b] != 0;
+    const bool act = LTV || a.active[b] != 0;
     if (__ballot(act) == 0ull) return;
     double* s = sh + grp * G::SLOT;
     const bool row = c < n;
@@ -335,7 +337,9 @@ __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KAr
     const double* Lp = a.LIN + (size_t)tile * a.N * NL * TILE + pl;
     double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + pl;
     double* kp = a.KFF + (size_t)tile * a.N * m * TILE + pl;
-    {
+    if constexpr (LTV) {
+        vx = 0.0;
+    } else {
         double target[n], xN[n];
         load_col<n>(a.TARGET + (size_t)tile * n * TILE + pl, target);
         load_col<n>(Xp + (size_t)a.N * n * TILE, xN);
@@ -400,6 +404,7 @@ __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KAr
         // ---- gains (every lane: Q_uu, Q_u, the inverse, k; lane i: column i of Q_ux and K, Q_x[i]).  Done before the
         // row phase so that Q_uu and its inverse (2 m^2 doubles) are dead when the rows of A^T V_xx come into registers.
         double Qux[m], Qu[m], k[m], Kc[m], KtQuu[m], g = 0.0, h = 0.0;
+        double Gi[LTV ? m * m : 1];                                                    // ltvlqr keeps G^-1 for the P update
         {
             double Quu[m * m], Quu_inv[m * m], Acol[n], Qx = 0.0;
 #pragma unroll
@@ -444,6 +449,10 @@ __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KAr
                 Qu[l] = lu + Qu[l];
             }
                 ok = Riccati<S>::inv_spd(Quu, Quu_inv) && ok;                              // :106
+            if constexpr (LTV) {
+#pragma unroll
+                for (int q = 0; q < m * m; ++q) Gi[q] = Quu_inv[q];
+            }
     #pragma unroll
             for (int l = 0; l < m; ++l) {                                              // :107-108
                 double acc = 0.0, acc2 = 0.0;
@@ -485,8 +494,10 @@ __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KAr
 #pragma unroll
                 for (int l = 0; l < m; ++l) Kp[((size_t)t * (m * n) + l * n + c) * TILE] = Kc[l];   // :112
             }
+            if constexpr (!LTV) {
 #pragma unroll
-            for (int l = 0; l < m; ++l) if (c == l) kp[((size_t)t * m + l) * TILE] = k[l];          // :111
+                for (int l = 0; l < m; ++l) if (c == l) kp[((size_t)t * m + l) * TILE] = k[l];      // :111
+            }
         }
         const double cur = g + h;                                                      // :117
         ecr_g += g; ecr_h += h; ecr += cur;                                            // :119-121
@@ -497,6 +508,28 @@ __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KAr
         for (int r = 0; r < n; ++r) Ri[r] = s[G::oT + cc * LD + r];                    // (A^T V_xx)[i][:]
 #pragma unroll
         for (int j = 0; j < n; ++j) Aw[j] = s[G::oAT + j * LD + cc];                   // own row of A_t again (its
+        double wl[LTV ? m : 1];                                                        // ltvlqr: (A'PB G^-1)[i][:]
+        if constexpr (LTV) {
+            double apb[m];
+#pragma unroll
+            for (int l = 0; l < m; ++l) apb[l] = 0.0;
+            static_for<0, n>([&](auto rc) {                                            // (A'PB)[i][l] = sum_r (A'P)[i][r] B[r][l]
+                constexpr int r = decltype(rc)::value;
+                static_for<0, m>([&](auto lc) {
+                    constexpr int l = decltype(lc)::value;
+                    constexpr char kd = S::B_pat[r * m + l];
+                    if constexpr (kd == 'x') fmac_row<r>(apb[l], Br[l], Ri[r]);
+                    else if constexpr (kd == '1') apb[l] = apb[l] + Ri[r];
+                });
+            });
+#pragma unroll
+            for (int l = 0; l < m; ++l) {
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < m; ++q) acc = __builtin_fma(apb[q], Gi[q * m + l], acc);
+                wl[l] = acc;
+            }
+        }
         static_for<0, n>([&](auto jc) {                                                // registers ended with the column phase)
             constexpr int j = decltype(jc)::value;
             double acc = 0.0;
@@ -507,6 +540,14 @@ __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KAr
                 else if constexpr (kd == '1') acc = acc + Ri[r];
             });
             const double Qxx = sQk[cc * n + j] + acc;
+            if constexpr (LTV) {                                                       // ltvlqr.py:27
+                double corr = 0.0;
+#pragma unroll
+                for (int l = 0; l < m; ++l) fmac_row<j>(corr, Qux[l], wl[l]);           // w[i][l] * (B'PA)[l][j]
+                const double Pij = Qxx - corr;
+                if (row) s[G::oT + c * LD + j] = Pij;
+                return;
+            }
             double t1 = 0.0, t2 = 0.0, t3 = 0.0;
 #pragma unroll
             for (int l = 0; l < m; ++l) fmac_row<j>(t1, Kc[l], Qux[l]);                // Q_ux[l][i] * K[l][j]
@@ -528,7 +569,11 @@ __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KAr
         step(t, A0, B0, u0, A1, B1, u1);
         if (t > 0) step(t - 1, A1, B1, u1, A0, B0, u0);
     }
-    if (act && c == 0) backward_epilogue(a, tile, pl, b, ecr, ecr_g, ecr_h, ok);
+    if constexpr (LTV) {
+        if (!ok && c == 0) a.status[b] = ILQR_STATUS_NUMERICAL;
+    } else {
+        if (act && c == 0) backward_epilogue(a, tile, pl, b, ecr, ecr_g, ecr_h, ok);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

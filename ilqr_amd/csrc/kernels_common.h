@@ -78,6 +78,7 @@ struct KArgs {
     int* ls_rounds;
     int ls_round;          // line search: round r evaluates trials [ls_j0, ls_j0 + W) (W is the launched kernel's width)
     int ls_j0;
+    int all_problems;      // k_linearize / the ltvlqr recursion: ignore the per-problem `active` flags of solve()
     int ls_last;           // no round follows: a search that fails here has run out of learning rate
     int* ls_list;          // [2][Bpad] problems still searching after a round (ping-pong by round parity)
     int* ls_count;         // [MAX_TRIALS] length of the list each round leaves (zeroed before round 0)

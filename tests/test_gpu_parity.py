@@ -330,6 +330,42 @@ def test_ltvlqr_vs_oracle_batch(amd, oracle):
         assert rel_err(K[b], Ko[b]) < TOL
 
 
+def test_ltvlqr_quadcopter_vs_oracle(amd, oracle):
+    """n = 12: the gain schedule runs on the lane-group recursion (k_linearize + k_riccati_grp<ltv>); trajectory = the
+    reference's quadcopter solve output, perturbed per problem.  No reference fixture exists for this case: the check is
+    against the CPU oracle, whose ltvlqr is pinned on the acrobot and pendulum fixtures."""
+    g = golden('quadcopter_solve')
+    rng = np.random.default_rng(4)
+    B, N = 9, 120
+    states = g['states'][None, :N + 1] + 1e-2 * rng.standard_normal((B, N + 1, 12))
+    inputs = g['inputs'][None, :N] + 1e-2 * rng.standard_normal((B, N, 4))
+    Qk, Rk, QT = 0.1 * np.eye(12), 0.01 * np.eye(4), 100 * np.eye(12)
+    _, A, Bf = amd.symbolic_dynamics_quadcopter()
+    K = amd.ltvlqr(states, inputs, A, Bf, Qk, Rk, QT, float(g['dt']), g['params'])
+    Ko = oracle.ltvlqr_batched('quadcopter', states, inputs, Qk, Rk, QT, float(g['dt']), g['params'])
+    assert K.shape == (B, N, 4, 12)
+    for b in range(B):
+        assert rel_err(K[b], Ko[b]) < TOL
+
+
+def test_ltvlqr_group_recursion_on_a_small_system(amd):
+    """the ltvlqr mode of the lane-group kernel forced on the acrobot (riccati = 2) against the one-lane kernel"""
+    from ilqr_amd import _lib
+    csv, g = golden('acrobot_csv'), golden('acrobot_ltvlqr')
+    B, N = 66, 300
+    rng = np.random.default_rng(8)
+    states = csv['states'][None, :N + 1] + 1e-2 * rng.standard_normal((B, N + 1, 4))
+    inputs = csv['inputs'][None, :N] + 1e-1 * rng.standard_normal((B, N, 1))
+    Ks = []
+    for riccati in (1, 2):
+        with _lib.Workspace('acrobot', N, B, float(g['dt']), riccati=riccati) as ws:
+            ws.set_weights(g['Qk'], g['Rk'], g['QT'])
+            ws.upload(_lib.F_PARAMS, g['params']); ws.upload(_lib.F_STATES, states); ws.upload(_lib.F_INPUTS, inputs)
+            ws.ltvlqr(); ws.sync()
+            Ks.append(ws.download(_lib.F_KFB))
+    assert rel_err(Ks[1], Ks[0]) < 1e-11
+
+
 # ------------------------------------------------------------------------------------------ tracking (SURVEY 8f #1)
 @pytest.mark.parametrize('system', ['acrobot', 'pendulum'])
 def test_tracking_rollout_examples(amd, system):
