@@ -9,8 +9,8 @@
 //     values.  Measured on the host against 80-bit sinl/cosl: max error 0.78 ulp over |x| < 5e5 (glibc: 0.52), 0.50 ulp near
 //     multiples of pi/2; it differs from glibc in 3 % of arguments, always by one ulp.
 //   * otherwise (huge, inf, nan): ocml sin()/cos(), out of line, reached through ONE branch per generated function.
-// Products n * piece must stay exact and un-fused where written; this file is compiled with -ffp-contract=off and uses
-// __builtin_fma only in the polynomial evaluation.
+// This file is compiled with -ffp-contract=off; every fused operation is an explicit __builtin_fma (the exact
+// products n * piece, the polynomials and the combination steps of the two kernels).  tools/trig_accuracy.cpp measures it.
 #ifndef ILQR_FAST_TRIG_H
 #define ILQR_FAST_TRIG_H
 
@@ -26,6 +26,17 @@ __device__ __attribute__((noinline)) ilqr_sc ilqr_sincos_slow(const double x)
     return r;
 }
 
+// x with its sign bit xor-ed with `sign` (0 or 0x80000000)
+__device__ __forceinline__ double ilqr_flip_sign(const double x, const unsigned sign)
+{
+    unsigned long long b;
+    __builtin_memcpy(&b, &x, 8);
+    b ^= (unsigned long long)sign << 32;
+    double y;
+    __builtin_memcpy(&y, &b, 8);
+    return y;
+}
+
 // fast path only; the caller patches arguments with !(|x| < 1e6) through ilqr_sincos_slow (one branch per function)
 __device__ __forceinline__ void ilqr_sincos_fast(const double x, double& s_out, double& c_out)
 {
@@ -39,24 +50,30 @@ __device__ __forceinline__ void ilqr_sincos_fast(const double x, double& s_out, 
                      C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
     const double fn = __builtin_rint(x * invpio2);
     const int q = (int)fn;
-    const double t = x - fn * pio2_1;            // exact product, exact or nearly exact difference
-    double w = fn * pio2_2;                      // exact product
+    const double t = __builtin_fma(-fn, pio2_1, x);          // fn * pio2_1 is exact, and so is this difference
+    double w = fn * pio2_2;                                   // exact product
     const double r = t - w;
-    w = fn * pio2_2t - ((t - r) - w);
+    w = __builtin_fma(fn, pio2_2t, -((t - r) - w));
     const double y0 = r - w;
-    const double y1 = (r - y0) - w;              // tail of the reduced argument
+    const double y1 = (r - y0) - w;                           // tail of the reduced argument
     const double z = y0 * y0;
     const double v = z * y0;
     const double rs = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2);
-    const double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
-    const double rc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
+    // y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1), the inner steps fused
+    const double ks = y0 - __builtin_fma(-v, S1, __builtin_fma(z, __builtin_fma(-v, rs, 0.5 * y1), -y1));
+    const double pc = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
     const double hz = 0.5 * z;
     const double wc = 1.0 - hz;
-    const double kc = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
+    // wc + (((1 - wc) - hz) + (z * z * pc - y0 * y1))
+    const double kc = wc + (((1.0 - wc) - hz) + __builtin_fma(z * z, pc, -(y0 * y1)));
+    // quadrant: swap on bit 0 of q; sin changes sign on bit 1 of q, cos on bit 1 of q + 1 (sign bits set by shifts,
+    // no compares)
     const double s = (q & 1) ? kc : ks;
     const double c = (q & 1) ? ks : kc;
-    s_out = (q & 2) ? -s : s;
-    c_out = ((q + 1) & 2) ? -c : c;
+    const unsigned ss = ((unsigned)q << 30) & 0x80000000u;
+    const unsigned sc = ((unsigned)(q + 1) << 30) & 0x80000000u;
+    s_out = ilqr_flip_sign(s, ss);
+    c_out = ilqr_flip_sign(c, sc);
 }
 
 // sin and cos of t = fl(a + b) -- the argument the reference hands to numpy -- from the pairs of a and b: angle addition

@@ -81,6 +81,9 @@ __global__ void __launch_bounds__(64) k_cost(const KArgs a)
 #ifndef CLOSED_LOOP_PREFETCH
 #define CLOSED_LOOP_PREFETCH 1
 #endif
+#ifndef CLOSED_LOOP_SCHED_BARRIER
+#define CLOSED_LOOP_SCHED_BARRIER 1
+#endif
 template <class S, bool STORE, bool CKPT, bool LINOUT = false>
 __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double* Xp, const double* Up, const double* Kp,
                                                     const double* kp, double* XOp, double* UOp, double* ckp,
@@ -142,6 +145,15 @@ __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double
                 store_lin<S>(Lp + (size_t)t * Lin<S>::n_lin * TILE, A, Bm);
             }
             {
+#if CLOSED_LOOP_SCHED_BARRIER
+                // refill AFTER the slot's last use (u pinned in place: the compiler otherwise sinks its computation below
+                // the loads and pays one register copy per loaded value and step): same registers, no copies
+                if constexpr (PREFETCH && !LINOUT) {
+#pragma unroll
+                    for (int j = 0; j < m; ++j) asm volatile("" : "+v"(u[j]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
                 const int tl = t + D < t1 ? t + D : t1 - 1;                            // slot d next holds step t + D
                 load_col<n>(Xp + (size_t)tl * n * TILE, xb[d]); load_col<m>(Up + (size_t)tl * m * TILE, ub[d]);
                 if constexpr (PREFETCH) { load_col<m * n>(Kp + (size_t)tl * (m * n) * TILE, K[d]); load_col<m>(kp + (size_t)tl * m * TILE, kf[d]); }
