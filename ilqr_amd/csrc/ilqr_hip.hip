@@ -103,7 +103,7 @@ struct ilqr_ws {
     hipEvent_t sub_start, sub_done[4];
     long long sub_tile0[5];
     double *XB, *CKPT, *LIN;
-    int split, grp, ck, n_seg, n_lin;
+    int split, grp, quad, ck, n_seg, n_lin;
     double *X, *U, *G, *KFB, *KFF, *XO, *UO, *INIT, *TARGET, *PARAMS, *WTS, *alphas, *alpha_pp, *cost, *new_cost, *dJ, *trace;
     int *active, *iters, *status, *acc_j, *ls_rounds, *accepts, *ls_list, *ls_count;
     void* staging;
@@ -363,6 +363,9 @@ int ws_riccati(ilqr_ws* ws, int it, int sub = -1)
     return run_pass(ws, KID_BACKWARD, it, "k_riccati", [&](auto S, const KArgs& a, hipStream_t st) {
         using T = decltype(S);
         if (ws->grp) hipLaunchKernelGGL(k_riccati_grp<T>, dim3((unsigned)(a.n_tiles * Grp<T>::GL)), dim3(64), 0, st, a);
+        else if (ws->quad) {
+            if constexpr (T::n <= 4) hipLaunchKernelGGL(k_riccati_quad<T>, dim3((unsigned)(a.n_tiles * 4)), dim3(64), 0, st, a);
+        }
         else hipLaunchKernelGGL(k_riccati<T>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
     }, sub);
 }
@@ -465,7 +468,7 @@ int validate_desc(const ilqr_desc* d)
     const int w = d->n_alpha_parallel;
     if (w != 0 && (w < 1 || w > 64 || (w & (w - 1)) != 0)) return fail(-1, "n_alpha_parallel must be 0 or a power of two <= 64");
     if (d->n_streams < 0 || d->n_streams > 4) return fail(-1, "n_streams must be 0 (default: 1) to 4");
-    if (d->riccati < 0 || d->riccati > 2) return fail(-1, "riccati must be 0 (auto), 1 (lane per problem) or 2 (lane group)");
+    if (d->riccati < 0 || d->riccati > 3) return fail(-1, "riccati must be 0 (auto), 1 (lane per problem), 2 (16-lane group) or 3 (4-lane quad)");
     if (d->pipeline < 0 || d->pipeline > 2) return fail(-1, "pipeline must be 0 (auto), 1 (fused) or 2 (split)");
     if (!(d->learning_speed > 0.0 && d->learning_speed < 1.0)) return fail(-1, "learning_speed must be in (0,1)");
     if (!(d->low_learning_rate > 0.0 && d->low_learning_rate < 1.0)) return fail(-1, "low_learning_rate must be in (0,1)");
@@ -628,6 +631,11 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
     // beyond (always through the split schedule, which provides LIN); riccati = 1 / 2 forces lane / group
     ws->grp = d->riccati == 2 || (d->riccati == 0 && ws->n > 4);
     if (ws->grp) ws->split = 1;
+    // four lanes per problem (k_riccati_quad): a shorter instruction chain per step on a chip the lane kernel leaves
+    // idle.  Measured on the acrobot (N = 3000): 4096 problems 1.87 -> 1.44 ms, 8192 1.88 -> 1.62, 12 288 1.93 -> 2.15
+    // (every lane of a quad loads the whole record), hence up to 128 tiles; riccati = 3 forces it (n <= 4)
+    ws->quad = !ws->grp && ws->n <= 4 && (d->riccati == 3 || (d->riccati == 0 && ws->n == 4 && ws->split && ws->tiles <= 128));
+    if (ws->quad) ws->split = 1;
     ws->ck = CKPT_INTERVAL;
     ws->n_seg = (ws->N + ws->ck - 1) / ws->ck;
     ws->n_lin = with_system(d->system_id, [&](auto S) { return Lin<decltype(S)>::n_lin; });

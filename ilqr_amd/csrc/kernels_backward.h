@@ -194,29 +194,43 @@ __global__ void __launch_bounds__(64) k_riccati(const KArgs a)
     // A_t, B_t, u_t of the next D steps are in flight while step t computes: one step (~0.5 us of dependent arithmetic)
     // is shorter than an HBM round trip, and one wave per SIMD has nothing else to hide it behind.
     constexpr int D = Lin<S>::n_lin + m <= 16 ? RICCATI_PREFETCH : 1;
-    double Ar[D][n * n], Br[D][n * m], ur[D][m];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const int tl = a.N - 1 - d > 0 ? a.N - 1 - d : 0;
-        load_lin<S>(Lp + (size_t)tl * Lin<S>::n_lin * TILE, Ar[d], Br[d]);
-        load_col<m>(Up + (size_t)tl * m * TILE, ur[d]);
+    auto one_step = [&](const int t, const double (&A)[n * n], const double (&Bm)[n * m], const double (&u)[m], auto&& refill) {
+        double k[m], K[m * n], g, h;
+        ok = Riccati<S>::step(A, Bm, u, Qk, Rk, a.quu_reg, Vx, Vxx, k, K, g, h) && ok;
+        refill();
+        if (act) {
+            store_col<m>(kp + (size_t)t * m * TILE, k);                                // :111
+            store_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K);                      // :112
+        }
+        const double cur = g + h;                                                      // :117
+        ecr_g += g; ecr_h += h; ecr += cur;                                            // :119-121
+    };
+    // the first N mod D steps one by one, then whole groups of D (no exit inside the unrolled group: an early exit
+    // there costs a register shuffle per step)
+    int t0 = a.N - 1;
+    for (const int rem = a.N % D; t0 >= a.N - rem; --t0) {
+        double A1[n * n], B1[n * m], u1[m];
+        load_lin<S>(Lp + (size_t)t0 * Lin<S>::n_lin * TILE, A1, B1);
+        load_col<m>(Up + (size_t)t0 * m * TILE, u1);
+        one_step(t0, A1, B1, u1, [] {});
     }
-    for (int t0 = a.N - 1; t0 >= 0; t0 -= D) {                                         // :82
+    double Ar[D][n * n], Br[D][n * m], ur[D][m];
+    if (t0 >= 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            load_lin<S>(Lp + (size_t)(t0 - d) * Lin<S>::n_lin * TILE, Ar[d], Br[d]);
+            load_col<m>(Up + (size_t)(t0 - d) * m * TILE, ur[d]);
+        }
+    }
+    for (; t0 >= 0; t0 -= D) {                                                         // :82
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int t = t0 - d;
-            if (t < 0) break;
-            double k[m], K[m * n], g, h;
-            ok = Riccati<S>::step(Ar[d], Br[d], ur[d], Qk, Rk, a.quu_reg, Vx, Vxx, k, K, g, h) && ok;
-            const int tl = t - D > 0 ? t - D : 0;                                      // slot d next holds step t - D
-            load_lin<S>(Lp + (size_t)tl * Lin<S>::n_lin * TILE, Ar[d], Br[d]);
-            load_col<m>(Up + (size_t)tl * m * TILE, ur[d]);
-            if (act) {
-                store_col<m>(kp + (size_t)t * m * TILE, k);                            // :111
-                store_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K);                  // :112
-            }
-            const double cur = g + h;                                                  // :117
-            ecr_g += g; ecr_h += h; ecr += cur;                                        // :119-121
+            one_step(t, Ar[d], Br[d], ur[d], [&] {
+                const int tl = t - D > 0 ? t - D : 0;                                  // slot d next holds step t - D
+                load_lin<S>(Lp + (size_t)tl * Lin<S>::n_lin * TILE, Ar[d], Br[d]);
+                load_col<m>(Up + (size_t)tl * m * TILE, ur[d]);
+            });
         }
     }
     if (act) backward_epilogue(a, tile, lane, b, ecr, ecr_g, ecr_h, ok);
@@ -285,6 +299,261 @@ __device__ __forceinline__ void static_for(F&& f)
         f(std::integral_constant<int, I>{});
         static_for<I + 1, N>(f);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_riccati_quad: the same recursion as k_riccati with FOUR lanes per problem (n <= 4), for batches that leave the chip
+// mostly idle (4096 problems = 64 waves of k_riccati on 1024 SIMDs, a pure instruction-issue chain per step).
+//   * lane c of a quad owns COLUMN c: V_xx[:, c], (A^T V_xx)[:, c], (B^T V_xx)[:, c], Q_xx[:, c], Q_ux[:, c], K[:, c],
+//     V_x[c].  The two places where a column needs the other lanes' columns -- (B^T V_xx) A, (A^T V_xx) A -- and the
+//     new V_x are all-gathers inside the quad: v_mov_b32_dpp quad_perm (DPP on 64-bit operands only has row_newbcast).
+//   * A_t, B_t, u_t are loaded whole by every lane (the quad reads the same addresses); in addition lane c loads ITS
+//     column of A_t through per-lane offsets, structural zeros / ones patched in from per-lane constants, and uses it
+//     densely: a product with an exact 0 or 1 rounds like the skipped / plain term of Riccati<S>::step, so K, k and the
+//     expected reductions are bit-identical to k_riccati for finite data (tested).
+//   * the small quantities (Q_u, Q_uu, its inverse, k, K, Q_ux) are computed by every lane.
+// A workgroup is one wave = 16 problems; a tile is 4 workgroups.
+// ------------------------------------------------------------------------------------------------
+#ifndef RICCATI_QUAD_PREFETCH
+#define RICCATI_QUAD_PREFETCH 6
+#endif
+template <int Q>
+__device__ __forceinline__ double bcast_quad(const double v)
+{
+    constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);                           // quad_perm:[Q,Q,Q,Q]
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// dense dot product in the order of acc_term: first term a product, the rest fused
+template <int CNT>
+__device__ __forceinline__ double dot_dense(const double (&a)[CNT], const double (&b)[CNT])
+{
+    double s = a[0] * b[0];
+#pragma unroll
+    for (int r = 1; r < CNT; ++r) s = __builtin_fma(a[r], b[r], s);
+    return s;
+}
+
+template <class S>
+__global__ void __launch_bounds__(64) k_riccati_quad(const KArgs a)
+{
+    constexpr int n = S::n, m = S::m, NL = Lin<S>::n_lin;
+    static_assert(n <= 4, "k_riccati_quad: one lane per column, four lanes per problem");
+    const long long tile = a.tile0 + (blockIdx.x >> 2);
+    const int lane = threadIdx.x;
+    const int c = (lane & 3) < n ? (lane & 3) : n - 1;                                 // lanes beyond n shadow the last column
+    const bool owner = (lane & 3) < n;
+    const int bl = ((blockIdx.x & 3) << 4) + (lane >> 2);                              // problem within the tile
+    const long long b = tile * TILE + bl;
+    const bool act = a.active[b] != 0;
+    if (__ballot(act) == 0ull) return;
+    double target[n], Qk[n * n], Rk[m * m], QT[n * n], Vx[n], Vc[n], Qkc[n];
+    load_col<n>(a.TARGET + (size_t)tile * n * TILE + bl, target);
+    load_uniform<n * n>(a.WTS, Qk);
+    load_uniform<m * m>(a.WTS + n * n, Rk);
+    load_uniform<n * n>(a.WTS + n * n + m * m, QT);                                    // :67
+    const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + bl;
+    const double* Up = a.U + (size_t)tile * a.N * m * TILE + bl;
+    const double* Lp = a.LIN + (size_t)tile * a.N * NL * TILE + bl;
+    double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + bl;
+    double* kp = a.KFF + (size_t)tile * a.N * m * TILE + bl;
+    terminal_value<S>(Xp + (size_t)a.N * n * TILE, target, QT, Vx);
+    // this lane's column of Q_T (= V_xx), of Q_k, and where its column of A_t sits in a LIN record
+    int aoff[n];
+    bool aisx[n];
+    double acst[n];
+#pragma unroll
+    for (int r = 0; r < n; ++r) {
+        Vc[r] = 0.0; Qkc[r] = 0.0; aoff[r] = 0; aisx[r] = false; acst[r] = 0.0;
+#pragma unroll
+        for (int q = 0; q < n; ++q)
+            if (c == q) {
+                Vc[r] = QT[r * n + q];
+                Qkc[r] = Qk[r * n + q];
+                const int li = lin_index<S, false>(r * n + q);
+                aisx[r] = li >= 0;
+                aoff[r] = li >= 0 ? li * TILE : 0;
+                acst[r] = li == -2 ? 1.0 : 0.0;
+            }
+    }
+    // rows of A with at least one general entry (only those are loaded per lane) / with only general entries
+    constexpr auto row_any_x = [](int r) { bool v = false; for (int q = 0; q < n; ++q) v = v || S::a_kind(r * n + q) == 'x'; return v; };
+    constexpr auto row_all_x = [](int r) { bool v = true; for (int q = 0; q < n; ++q) v = v && S::a_kind(r * n + q) == 'x'; return v; };
+    double ecr = 0.0, ecr_g = 0.0, ecr_h = 0.0;
+    bool ok = true;
+    constexpr int D = RICCATI_QUAD_PREFETCH;
+    auto fetch = [&](const int tl, double (&A)[n * n], double (&Bm)[n * m], double (&u)[m], double (&Acr)[n]) {
+        const double* l = Lp + (size_t)tl * NL * TILE;
+        load_lin<S>(l, A, Bm);
+        load_col<m>(Up + (size_t)tl * m * TILE, u);
+#pragma unroll
+        for (int r = 0; r < n; ++r) Acr[r] = row_any_x(r) ? l[aoff[r]] : 0.0;
+    };
+    // one time step; refill() is called as soon as the step's inputs are consumed
+    auto one_step = [&](const int t, const double (&A)[n * n], const double (&Bm)[n * m], const double (&u)[m],
+                        const double (&Acr)[n], auto&& refill) {
+        double acol[n];
+#pragma unroll
+        for (int r = 0; r < n; ++r) acol[r] = !row_any_x(r) ? acst[r] : (row_all_x(r) ? Acr[r] : (aisx[r] ? Acr[r] : acst[r]));
+        // :99  Q_x[c] = (A.T V_x)[c]
+        const double Qxc = dot_dense<n>(acol, Vx);
+        // :93,:100  Q_u = R_k u + B.T V_x
+        double Qu[m], BtVc[m], BtV[m * n], Qux[m * n], Quxc[m], Quu[m * m], Quu_inv[m * m];
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+            double lu = 0.0;
+#pragma unroll
+            for (int l = 0; l < m; ++l) lu = __builtin_fma(Rk[j * m + l], u[l], lu);
+            double s = 0.0; bool first = true;
+#pragma unroll
+            for (int r = 0; r < n; ++r) acc_term(s, first, S::b_kind(r * m + j), Bm[r * m + j], Vx[r]);
+            Qu[j] = lu + s;
+        }
+        // (B.T V_xx)[:, c], then the whole of it from the quad
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+            double s = 0.0; bool first = true;
+#pragma unroll
+            for (int r = 0; r < n; ++r) acc_term(s, first, S::b_kind(r * m + j), Bm[r * m + j], Vc[r]);
+            BtVc[j] = s;
+        }
+#pragma unroll
+        for (int j = 0; j < m; ++j)
+            static_for<0, n>([&](auto R) { constexpr int r = decltype(R)::value; BtV[j * n + r] = bcast_quad<r>(BtVc[j]); });
+        // :101  Q_ux = (B.T V_xx) A (whole, and this lane's column from its own column of A); :102  Q_uu
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+            double bt[n];
+#pragma unroll
+            for (int r = 0; r < n; ++r) bt[r] = BtV[j * n + r];
+            Quxc[j] = dot_dense<n>(acol, bt);
+#pragma unroll
+            for (int q = 0; q < n; ++q) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::a_kind(r * n + q), A[r * n + q], BtV[j * n + r]);
+                Qux[j * n + q] = s;
+            }
+#pragma unroll
+            for (int l = 0; l < m; ++l) {
+                double s = 0.0; bool first = true;
+#pragma unroll
+                for (int r = 0; r < n; ++r) acc_term(s, first, S::b_kind(r * m + l), Bm[r * m + l], BtV[j * n + r]);
+                Quu[j * m + l] = Rk[j * m + l] + s;
+            }
+            Quu[j * m + j] += a.quu_reg;
+        }
+        // :103  Q_xx[:, c] = Q_k[:, c] + ((A.T V_xx) A)[:, c]; row i of A.T V_xx gathered from the quad
+        double Qxxc[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double s = 0.0; bool first = true;
+#pragma unroll
+            for (int r = 0; r < n; ++r) acc_term(s, first, S::a_kind(r * n + i), A[r * n + i], Vc[r]);
+            double row[n];
+            static_for<0, n>([&](auto R) { constexpr int r = decltype(R)::value; row[r] = bcast_quad<r>(s); });
+            Qxxc[i] = Qkc[i] + dot_dense<n>(acol, row);
+        }
+        refill();                                                                  // the step's inputs are consumed
+        // :106-108  gains
+        double k[m], K[m * n], Kc[m];
+        ok = Riccati<S>::inv_spd(Quu, Quu_inv) && ok;
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+            double s = 0.0, tc = 0.0;
+#pragma unroll
+            for (int l = 0; l < m; ++l) s = __builtin_fma(-Quu_inv[j * m + l], Qu[l], s);
+            k[j] = s;
+#pragma unroll
+            for (int l = 0; l < m; ++l) tc = __builtin_fma(-Quu_inv[j * m + l], Quxc[l], tc);
+            Kc[j] = tc;
+#pragma unroll
+            for (int q = 0; q < n; ++q) {
+                double t2 = 0.0;
+#pragma unroll
+                for (int l = 0; l < m; ++l) t2 = __builtin_fma(-Quu_inv[j * m + l], Qux[l * n + q], t2);
+                K[j * n + q] = t2;
+            }
+        }
+        if (act && owner) {
+#pragma unroll
+            for (int j = 0; j < m; ++j) Kp[((size_t)t * (m * n) + j * n + c) * TILE] = Kc[j];   // :112
+            if (c == 0) store_col<m>(kp + (size_t)t * m * TILE, k);                              // :111
+        }
+        // :115-116  expected reduction terms
+        double g = 0.0, h = 0.0;
+#pragma unroll
+        for (int j = 0; j < m; ++j) g = __builtin_fma(-Qu[j], k[j], g);
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < m; ++i) s = __builtin_fma(0.5 * k[i], Quu[i * m + j], s);
+            h = __builtin_fma(s, k[j], h);
+        }
+        const double cur = g + h;                                                  // :117
+        ecr_g += g; ecr_h += h; ecr += cur;                                        // :119-121
+        // :124-125  value function update (four-term forms, no symmetrisation)
+        double KtQuu[n * m], KtQuuc[m];
+#pragma unroll
+        for (int l = 0; l < m; ++l) {
+            double sc = 0.0;
+#pragma unroll
+            for (int j = 0; j < m; ++j) sc = __builtin_fma(Kc[j], Quu[j * m + l], sc);
+            KtQuuc[l] = sc;
+#pragma unroll
+            for (int i = 0; i < n; ++i) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < m; ++j) s = __builtin_fma(K[j * n + i], Quu[j * m + l], s);
+                KtQuu[i * m + l] = s;
+            }
+        }
+        {
+            double v1 = 0.0, v2 = 0.0, v3 = 0.0;
+#pragma unroll
+            for (int l = 0; l < m; ++l) v1 = __builtin_fma(KtQuuc[l], k[l], v1);
+#pragma unroll
+            for (int j = 0; j < m; ++j) v2 = __builtin_fma(Kc[j], Qu[j], v2);
+#pragma unroll
+            for (int j = 0; j < m; ++j) v3 = __builtin_fma(Quxc[j], k[j], v3);
+            const double Vxc = ((Qxc + v1) + v2) + v3;
+            static_for<0, n>([&](auto R) { constexpr int r = decltype(R)::value; Vx[r] = bcast_quad<r>(Vxc); });
+        }
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+            for (int j = 0; j < m; ++j) t1 = __builtin_fma(Qux[j * n + i], Kc[j], t1);
+#pragma unroll
+            for (int j = 0; j < m; ++j) t2 = __builtin_fma(K[j * n + i], Quxc[j], t2);
+#pragma unroll
+            for (int l = 0; l < m; ++l) t3 = __builtin_fma(KtQuu[i * m + l], Kc[l], t3);
+            Vc[i] = ((Qxxc[i] + t1) + t2) + t3;
+        }
+    };
+    // the first N mod D steps one by one, then whole groups of D steps from a ring of D slots (the group loop has no
+    // exit inside its unrolled body: an early exit there costs a register shuffle per step)
+    int t0 = a.N - 1;
+    for (const int rem = a.N % D; t0 >= a.N - rem; --t0) {
+        double A1[n * n], B1[n * m], u1[m], Ac1[n];
+        fetch(t0, A1, B1, u1, Ac1);
+        one_step(t0, A1, B1, u1, Ac1, [] {});
+    }
+    double Ar[D][n * n], Br[D][n * m], ur[D][m], Ac[D][n];
+    if (t0 >= 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) fetch(t0 - d, Ar[d], Br[d], ur[d], Ac[d]);
+    }
+    for (; t0 >= 0; t0 -= D) {                                                         // :82
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int t = t0 - d;
+            one_step(t, Ar[d], Br[d], ur[d], Ac[d], [&] { fetch(t - D > 0 ? t - D : 0, Ar[d], Br[d], ur[d], Ac[d]); });
+        }
+    }
+    if (act && (lane & 3) == 0) backward_epilogue(a, tile, bl, b, ecr, ecr_g, ecr_h, ok);
 }
 
 // LTV = true: the ltvlqr recursion (ltvlqr.py:14-27) on the same lane mapping -- no V_x, k or expected reductions, the

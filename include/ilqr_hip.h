@@ -63,8 +63,10 @@ typedef struct ilqr_desc {
                                      ranges), each with its own launch chain on its own HIP stream, so that one sub-batch's
                                      horizon-sequential kernels overlap another's line search.  0/1: one chain; max 4.
                                      Results do not depend on it. */
-    int32_t riccati;              /* mapping of the backward recursion: 0 auto (one lane per problem for n <= 4, a group of
-                                     lanes with LDS hand-offs for larger n), 1 lane, 2 group.  Group implies pipeline 2. */
+    int32_t riccati;              /* mapping of the backward recursion: 0 auto (n <= 4: one lane per problem, or four lanes
+                                     per problem for n = 4 in split-pipeline batches of up to 8192 problems; larger n: a row
+                                     of 16 lanes), 1 lane, 2 row of 16 lanes, 3 four lanes (n <= 4).  2 and 3 imply
+                                     pipeline 2.  1 and 3 give bit-identical results. */
 } ilqr_desc;
 
 void ilqr_desc_default(ilqr_desc* d);

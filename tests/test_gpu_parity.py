@@ -286,6 +286,28 @@ def test_group_riccati_matches_lane_riccati(amd, system):
         assert rel_err(a, b) < 1e-11
 
 
+@pytest.mark.parametrize('system', ['pendulum', 'double_integrator', 'acrobot', 'cartpole', 'car', 'double_pendulum'])
+def test_quad_riccati_is_bitwise_the_lane_riccati(amd, system):
+    """four lanes per problem (k_riccati_quad, the default for n = 4 in batches of up to 16 384 problems) against one lane
+    per problem: columns are evaluated densely with exact zeros and ones where the lane kernel skips terms, which rounds
+    identically -- every output of a 4-iteration solve is bit-identical"""
+    from ilqr_amd import _lib
+    g, init, guess = random_batch(system, 70, 130, seed=4)
+    outs = []
+    for riccati in (1, 3):
+        ws = amd.Workspace(system, 130, 70, float(g['dt']), want_trace=True, n_iterations=4, pipeline=2, riccati=riccati)
+        ws.set_weights(g['Qk'], g['Rk'], g['QT'])
+        for f, a in ((_lib.F_PARAMS, g['params']), (_lib.F_INIT, init), (_lib.F_TARGET, g['target']), (_lib.F_GUESS, guess)):
+            ws.upload(f, a)
+        ws.solve()
+        ws.sync()
+        outs.append([ws.download(f) for f in (_lib.F_STATES, _lib.F_INPUTS, _lib.F_KFB, _lib.F_KFF, _lib.F_COST, _lib.F_DJ,
+                                              _lib.F_STATUS, _lib.F_ITERS, _lib.F_TRACE)])
+        assert np.all(ws.download(_lib.F_STATUS) != 3)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 @pytest.mark.parametrize('pipeline', [1, 2])
 def test_sub_batches_on_streams_do_not_change_results(amd, pipeline):
     """solve() split into 3 independent sub-batches (uneven tile ranges: 200 problems = 4 tiles) on 3 HIP streams"""
