@@ -4,6 +4,9 @@
 // ------------------------------------------------------------------------------------------------
 // k_rollout: ilqr.py:30-47 with compute_cost (:49-62) fused.  One lane per problem, one wave per tile.
 // ------------------------------------------------------------------------------------------------
+#ifndef ROLLOUT_PREFETCH
+#define ROLLOUT_PREFETCH 8
+#endif
 template <class S>
 __global__ void __launch_bounds__(64) k_rollout(const KArgs a)
 {
@@ -27,15 +30,40 @@ __global__ void __launch_bounds__(64) k_rollout(const KArgs a)
         store_col<n>(Xp, x0);
     }
     double cost = 0.0;
-    for (int t = 0; t < a.N; ++t) {
-        double u[m], xn[n];
-        load_col<m>(Gp + (size_t)t * m * TILE, u);
+    auto one_step = [&](const int t, const double (&u)[m]) {
+        double xn[n];
         cost = cost + input_cost<m>(u, Rk);
         S::f(x, u, a.dt, p, xn);
 #pragma unroll
         for (int i = 0; i < n; ++i) x[i] = xn[i];
         store_col<n>(Xp + (size_t)(t + 1) * n * TILE, x);                              // :39
         store_col<m>(Up + (size_t)t * m * TILE, u);                                    // :40
+    };
+    // the guess of the next D steps is in flight (one step of f is shorter than an HBM round trip): the first N mod D
+    // steps one by one, then whole groups of D from a ring
+    constexpr int D = ROLLOUT_PREFETCH;
+    int t0 = 0;
+    for (const int rem = a.N % D; t0 < rem; ++t0) {
+        double u[m];
+        load_col<m>(Gp + (size_t)t0 * m * TILE, u);
+        one_step(t0, u);
+    }
+    double ur[D][m];
+    if (t0 < a.N) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) load_col<m>(Gp + (size_t)(t0 + d) * m * TILE, ur[d]);
+    }
+    for (; t0 < a.N; t0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int t = t0 + d;
+            double u[m];
+#pragma unroll
+            for (int j = 0; j < m; ++j) u[j] = ur[d][j];
+            const int tl = t + D < a.N ? t + D : a.N - 1;
+            load_col<m>(Gp + (size_t)tl * m * TILE, ur[d]);
+            one_step(t, u);
+        }
     }
     cost = cost + terminal_cost<n>(x, target, QT);
     a.cost[b] = cost;

@@ -9,7 +9,7 @@ address) the factor is an upper bound: narrow requests may be tallied at their t
 import csv, glob, json, os, sys, collections
 
 def short(name):
-    for k in ('k_linesearch', 'k_riccati_grp', 'k_riccati', 'k_accept_par', 'k_accept_lin', 'k_save_boundaries', 'k_linearize', 'k_rollout', 'k_cost', 'k_backward', 'k_forward', 'k_ltvlqr'):
+    for k in ('k_linesearch', 'k_riccati_grp', 'k_riccati_quad', 'k_riccati', 'k_accept_par', 'k_accept_lin', 'k_save_boundaries', 'k_linearize', 'k_rollout', 'k_cost', 'k_backward', 'k_forward', 'k_ltvlqr'):
         if k + '<' in name or k + '(' in name:
             return k
     return None
