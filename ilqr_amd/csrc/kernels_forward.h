@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(64) k_cost(const KArgs a)
 #define ACCEPT_PREFETCH 1
 #endif
 #ifndef CLOSED_LOOP_PREFETCH
-#define CLOSED_LOOP_PREFETCH 1
+#define CLOSED_LOOP_PREFETCH 3
 #endif
 #ifndef CLOSED_LOOP_SCHED_BARRIER
 #define CLOSED_LOOP_SCHED_BARRIER 1
@@ -138,64 +138,71 @@ __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double
         if constexpr (PREFETCH) { load_col<m * n>(Kp + (size_t)tl * (m * n) * TILE, K[d]); load_col<m>(kp + (size_t)tl * m * TILE, kf[d]); }
     }
     int next_ck = CKPT ? a.ck : 0;
-    for (int tb = t0; tb < t1; tb += D) {
+    auto one_step = [&](const int t, const int d, const bool refill) __attribute__((always_inline)) {
+        if constexpr (!PREFETCH) {
+            load_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K[d]);
+            load_col<m>(kp + (size_t)t * m * TILE, kf[d]);
+        }
+        if constexpr (CKPT) {
+            if (t == next_ck) {                                                    // state entering segment t / ck
+                double* c = ckp + (size_t)(t / a.ck) * n * TILE;
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int t = tb + d;
-            if (t >= t1) break;
-            if constexpr (!PREFETCH) {
-                load_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K[d]);
-                load_col<m>(kp + (size_t)t * m * TILE, kf[d]);
+                for (int i = 0; i < n; ++i) c[(size_t)i * TILE] = x[i];
+                next_ck += a.ck;
             }
-            if constexpr (CKPT) {
-                if (t == next_ck) {                                                    // state entering segment t / ck
-                    double* c = ckp + (size_t)(t / a.ck) * n * TILE;
+        }
+        double u[m], xn[n];
 #pragma unroll
-                    for (int i = 0; i < n; ++i) c[(size_t)i * TILE] = x[i];
-                    next_ck += a.ck;
-                }
-            }
-            double u[m], xn[n];
+        for (int j = 0; j < m; ++j) {
+            const double ff = alpha * kf[d][j];                                    // :146
+            double fb = 0.0;                                                       // :147
 #pragma unroll
-            for (int j = 0; j < m; ++j) {
-                const double ff = alpha * kf[d][j];                                    // :146
-                double fb = 0.0;                                                       // :147
+            for (int i = 0; i < n; ++i) fb = __builtin_fma(K[d][j * n + i], x[i] - xb[d][i], fb);
+            u[j] = (ub[d][j] + fb) + ff;                                           // :148
+        }
+        if constexpr (LINOUT) {                                                    // :96-97 for the next backward pass
+            double xl[n], A[n * n], Bm[n * m];
 #pragma unroll
-                for (int i = 0; i < n; ++i) fb = __builtin_fma(K[d][j * n + i], x[i] - xb[d][i], fb);
-                u[j] = (ub[d][j] + fb) + ff;                                           // :148
-            }
-            if constexpr (LINOUT) {                                                    // :96-97 for the next backward pass
-                double xl[n], A[n * n], Bm[n * m];
-#pragma unroll
-                for (int i = 0; i < n; ++i) xl[i] = t == 0 ? xb[d][i] : x[i];          // row 0 as stored (quirk Q1), else x_t
-                S::A(xl, u, a.dt, p, A);
-                S::B(xl, u, a.dt, p, Bm);
-                store_lin<S>(Lp + (size_t)t * Lin<S>::n_lin * TILE, A, Bm);
-            }
-            {
+            for (int i = 0; i < n; ++i) xl[i] = t == 0 ? xb[d][i] : x[i];          // row 0 as stored (quirk Q1), else x_t
+            S::A(xl, u, a.dt, p, A);
+            S::B(xl, u, a.dt, p, Bm);
+            store_lin<S>(Lp + (size_t)t * Lin<S>::n_lin * TILE, A, Bm);
+        }
+        {
 #if CLOSED_LOOP_SCHED_BARRIER
-                // refill AFTER the slot's last use (u pinned in place: the compiler otherwise sinks its computation below
-                // the loads and pays one register copy per loaded value and step): same registers, no copies
-                if constexpr (PREFETCH && !LINOUT) {
+            // refill AFTER the slot's last use (u pinned in place: the compiler otherwise sinks its computation below
+            // the loads and pays one register copy per loaded value and step): same registers, no copies
+            if constexpr (PREFETCH && !LINOUT) {
 #pragma unroll
-                    for (int j = 0; j < m; ++j) asm volatile("" : "+v"(u[j]));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                for (int j = 0; j < m; ++j) asm volatile("" : "+v"(u[j]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #endif
-                const int tl = t + D < t1 ? t + D : t1 - 1;                            // slot d next holds step t + D
+            if (refill) {
+                const int tl = t + D < t1 ? t + D : t1 - 1;                        // slot d next holds step t + D
                 load_col<n>(Xp + (size_t)tl * n * TILE, xb[d]); load_col<m>(Up + (size_t)tl * m * TILE, ub[d]);
                 if constexpr (PREFETCH) { load_col<m * n>(Kp + (size_t)tl * (m * n) * TILE, K[d]); load_col<m>(kp + (size_t)tl * m * TILE, kf[d]); }
             }
-            cost = cost + input_cost<m>(u, Rk);
-            S::f(x, u, a.dt, p, xn);                                                   // :151
-#pragma unroll
-            for (int i = 0; i < n; ++i) x[i] = xn[i];
-            if constexpr (STORE) {
-                store_col<m>(UOp + (size_t)t * m * TILE, u);                           // :154
-                store_col<n>(XOp + (size_t)(t + 1) * n * TILE, x);                     // :153
-            }
         }
+        cost = cost + input_cost<m>(u, Rk);
+        S::f(x, u, a.dt, p, xn);                                                   // :151
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = xn[i];
+        if constexpr (STORE) {
+            store_col<m>(UOp + (size_t)t * m * TILE, u);                           // :154
+            store_col<n>(XOp + (size_t)(t + 1) * n * TILE, x);                     // :153
+        }
+    };
+    // whole groups of D steps with no exit inside the unrolled group (an early exit there costs a register shuffle per
+    // step), then the last (t1 - t0) mod D steps from the slots the clamped refills left in place
+    int tb = t0;
+    for (; tb + D <= t1; tb += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) one_step(tb + d, d, true);
     }
+#pragma unroll
+    for (int d = 0; d + 1 < D; ++d)
+        if (tb + d < t1) one_step(tb + d, d, false);
     return cost;
 }
 
