@@ -423,6 +423,7 @@ int ws_linesearch(ilqr_ws* ws, int sub = -1)
                 case 32: launch_ls<T, 32>(s, a, ck); break;
                 default: launch_ls<T, 64>(s, a, ck); break;
             }
+            if (!a.ls_last) hipLaunchKernelGGL(k_ls_compact, dim3((unsigned)((a.n_tiles * TILE + 1023) / 1024)), dim3(1024), 0, s, a);
         }, sub, false);
         if (rc) return rc;
         j0 += Wr;

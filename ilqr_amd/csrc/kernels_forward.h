@@ -322,6 +322,7 @@ __device__ __forceinline__ double closed_loop_staged(const KArgs& a, double* sw,
 #ifndef LS_WAVES_SMALL
 #define LS_WAVES_SMALL 2
 #endif
+constexpr int LS_STILL_SEARCHING = -2;   // acc_j between rounds: no trial accepted yet, more rounds to come
 template <class S>
 constexpr int ls_waves_per_simd()
 {
@@ -406,13 +407,39 @@ __global__ void __launch_bounds__(W == 64 ? 512 : 256, ls_waves_per_simd<S>()) k
         if (gm != 0ull) {
             a.acc_j[b] = a.ls_j0 + first;
             a.new_cost[b] = cwin;
-        } else if (!a.ls_last) {                                                   // :200-202, next round's list
-            const int slot = atomicAdd(a.ls_count + r, 1);
-            a.ls_list[(size_t)(r & 1) * a.Bpad + a.tile0 * TILE + slot] = (int)b;
+        } else if (!a.ls_last) {                                                   // :200-202: k_ls_compact lists it for the next round
+            a.acc_j[b] = LS_STILL_SEARCHING;
         } else {                                                                   // :204 learning rate ran out
             a.acc_j[b] = -1;
             a.new_cost[b] = __builtin_nan("");
         }
+    }
+}
+
+// The list of the next round: the problems the round just run left searching, in ascending order inside each chunk of
+// 1024 problems (one atomic per chunk reserves its range).  Order matters for memory only: neighbours in the list are
+// neighbours in a tile, so the lanes of the next round's workgroups share 128-byte lines the way round 0's do
+// (appending from the search kernel itself, in completion order, made round 1 fetch 4-8x its algorithmic bytes).
+__global__ void __launch_bounds__(1024) k_ls_compact(const KArgs a)
+{
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
+    const long long b = a.tile0 * TILE + i;
+    const bool f = i < a.n_tiles * TILE && a.active[b] != 0 && a.acc_j[b] == LS_STILL_SEARCHING;
+    const unsigned long long mask = __ballot(f);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) wsum[wave] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) { const int c = wsum[w]; wsum[w] = tot; tot += c; }
+        base = tot ? atomicAdd(a.ls_count + a.ls_round, tot) : 0;
+    }
+    __syncthreads();
+    if (f) {
+        const int slot = base + wsum[wave] + __popcll(mask & ((1ull << lane) - 1ull));
+        a.ls_list[(size_t)(a.ls_round & 1) * a.Bpad + a.tile0 * TILE + slot] = (int)b;
     }
 }
 
