@@ -218,7 +218,11 @@ def main():
 
     total_solves = B * world * args.steps
     value = total_solves / elapsed
-    pass_ms = sum(kern[k_]['ms_per_pass'] for k_ in ('backward', 'linesearch', 'accept', 'linearize') if k_ in kern)
+    # one backward + line search + accept pass, from the wall clock of the step (the accept step of iteration i and the
+    # recursion of iteration i + 1 run overlapped on two streams: their per-kernel times below overlap, the sum would
+    # count that time twice): (step - initial rollout - initial linearisation) / iterations
+    once_ms = sum(kern[k_]['ms_per_pass'] for k_ in ('rollout', 'linearize') if k_ in kern)
+    pass_ms = (1e3 * elapsed / args.steps - once_ms) / max(args.iterations, 1)
     out = {
         'metric': 'iLQR solves/sec (fixed iters, batched)', 'value': round(value, 2), 'unit': 'solves/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),

@@ -32,7 +32,7 @@ class Desc(C.Structure):
                 ('n_iterations', C.c_int32), ('n_alpha_parallel', C.c_int32), ('zero_first_state', C.c_int32),
                 ('device', C.c_int32), ('learning_speed', C.c_double), ('low_learning_rate', C.c_double),
                 ('low_expected_reduction', C.c_double), ('armijo_threshold', C.c_double), ('quu_reg', C.c_double),
-                ('target_batched', C.c_int32), ('params_batched', C.c_int32), ('pipeline', C.c_int32), ('n_streams', C.c_int32), ('riccati', C.c_int32)]
+                ('target_batched', C.c_int32), ('params_batched', C.c_int32), ('pipeline', C.c_int32), ('n_streams', C.c_int32), ('riccati', C.c_int32), ('overlap', C.c_int32)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -139,7 +139,7 @@ def system_dims(system):
 
 def make_desc(system, N, B, dt, n_iterations=0, n_alpha_parallel=0, zero_first_state=True, device=0,
               target_batched=False, params_batched=False, learning_speed=0.95, low_learning_rate=0.05,
-              low_expected_reduction=1e-3, armijo_threshold=0.1, quu_reg=0.0, pipeline=0, n_streams=0, riccati=0):
+              low_expected_reduction=1e-3, armijo_threshold=0.1, quu_reg=0.0, pipeline=0, n_streams=0, riccati=0, overlap=0):
     d = Desc()
     lib().ilqr_desc_default(C.byref(d))
     d.system_id = SYSTEM_IDS[system] if isinstance(system, str) else int(system)
@@ -160,6 +160,7 @@ def make_desc(system, N, B, dt, n_iterations=0, n_alpha_parallel=0, zero_first_s
     d.pipeline = int(pipeline)
     d.n_streams = int(n_streams)
     d.riccati = int(riccati)
+    d.overlap = int(overlap)
     return d
 
 

@@ -23,6 +23,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <type_traits>
 #include <vector>
@@ -92,6 +93,10 @@ constexpr int CKPT_INTERVAL = 64;   // time steps between line-search checkpoint
 
 }  // namespace
 
+#ifndef ILQR_OVERLAP_CHUNKS
+#define ILQR_OVERLAP_CHUNKS 10
+#endif
+constexpr int OVERLAP_CHUNKS = ILQR_OVERLAP_CHUNKS;   // at most; a chunk is at least 4 segments of the horizon
 struct ilqr_ws {
     ilqr_desc d;
     int n, m, np, N, W, n_trials, want_trace;
@@ -103,7 +108,10 @@ struct ilqr_ws {
     hipEvent_t sub_start, sub_done[4];
     long long sub_tile0[5];
     double *XB, *CKPT, *LIN;
-    int split, grp, quad, ck, n_seg, n_lin;
+    int split, grp, quad, overlap, n_chunks, ck, n_seg, n_lin;
+    hipStream_t pipe_stream;                 // overlap: the Riccati chunks run here, the accept chunks on `stream`
+    hipEvent_t pipe_ev[OVERLAP_CHUNKS], pipe_done;
+    double* VST;
     double *X, *U, *G, *KFB, *KFF, *XO, *UO, *INIT, *TARGET, *PARAMS, *WTS, *alphas, *alpha_pp, *cost, *new_cost, *dJ, *trace;
     int *active, *iters, *status, *acc_j, *ls_rounds, *accepts, *ls_list, *ls_count;
     void* staging;
@@ -133,6 +141,7 @@ KArgs make_args(ilqr_ws* ws, int it)
     a.alpha_pp = ws->alpha_pp; a.cost = ws->cost; a.new_cost = ws->new_cost; a.dJ = ws->dJ; a.active = ws->active;
     a.iters = ws->iters; a.status = ws->status; a.acc_j = ws->acc_j; a.ls_rounds = ws->ls_rounds;
     a.ls_round = 0; a.ls_list = ws->ls_list; a.ls_count = ws->ls_count;
+    a.seg_lo = 0; a.seg_cnt = ws->n_seg; a.t_lo = 0; a.t_hi = ws->N; a.piped = 0; a.VST = ws->VST;
     a.accepts = ws->accepts; a.trace = ws->want_trace ? ws->trace : nullptr; a.Bpad = ws->Bpad;
     return a;
 }
@@ -377,6 +386,54 @@ int ws_accept_lin(ilqr_ws* ws, int it, int sub = -1)
         hipLaunchKernelGGL(k_accept_lin<decltype(S)>, grid, dim3(64), 0, st, a);
     }, sub);
 }
+// accept of iteration `it` and the Riccati recursion of iteration it + 1, overlapped: the accept step is parallel over
+// segments of the horizon, the recursion walks the horizon from its end -- so the accept runs in chunks, last segments
+// first, on the workspace stream, and each chunk of the recursion (k_riccati_quad over the same steps, value function
+// handed on through VST) follows its accept chunk on a second stream while the earlier segments are still being
+// accepted.  Same kernels, same arithmetic, same results; only the first accept chunk is not hidden.
+int ws_accept_riccati_overlapped(ilqr_ws* ws, int it)
+{
+    if (!ws) return fail(-1, "null workspace");
+    int rc = set_device(ws);
+    if (rc) return rc;
+    KArgs aa = make_args(ws, it), ar = make_args(ws, it + 1);
+    if (aa.n_tiles <= 0) return 0;
+    ar.piped = 1;
+    hipStream_t A = ws->stream, B = ws->pipe_stream;
+    return with_system(ws->d.system_id, [&](auto S) {
+        using T = decltype(S);
+        if constexpr (T::n <= 4) {
+            int rc2 = 0;
+            {
+                ProfScope pa(ws, KID_ACCEPT, A);
+                hipLaunchKernelGGL(k_save_boundaries, dim3((unsigned)(aa.n_tiles * ws->n_seg)), dim3(64), 0, A, aa, (int)T::n);
+                std::unique_ptr<ProfScope> pb;
+                const int C = ws->n_chunks;
+                for (int c = C - 1; c >= 0 && !rc2; --c) {
+                    const int s_lo = (int)((long long)ws->n_seg * c / C), s_hi = (int)((long long)ws->n_seg * (c + 1) / C);
+                    if (s_hi <= s_lo) continue;
+                    aa.seg_lo = s_lo; aa.seg_cnt = s_hi - s_lo;
+                    hipLaunchKernelGGL(k_accept_lin<T>, dim3((unsigned)(aa.n_tiles * aa.seg_cnt)), dim3(64), 0, A, aa);
+                    if ((rc2 = check_launch("k_accept_lin"))) break;
+                    if (hipEventRecord(ws->pipe_ev[c], A) != hipSuccess || hipStreamWaitEvent(B, ws->pipe_ev[c], 0) != hipSuccess) {
+                        rc2 = fail(-100, "overlap: event record / wait failed");
+                        break;
+                    }
+                    if (!pb) pb.reset(new ProfScope(ws, KID_BACKWARD, B));
+                    ar.t_lo = s_lo * ws->ck;
+                    ar.t_hi = s_hi * ws->ck < ws->N ? s_hi * ws->ck : ws->N;
+                    hipLaunchKernelGGL(k_riccati_quad<T>, dim3((unsigned)(ar.n_tiles * 4)), dim3(64), 0, B, ar);
+                    rc2 = check_launch("k_riccati_quad");
+                }
+            }   // the accept scope closes on A here; pb closed on B when it went out of scope above
+            if (hipEventRecord(ws->pipe_done, B) != hipSuccess || hipStreamWaitEvent(A, ws->pipe_done, 0) != hipSuccess)
+                return fail(-100, "overlap: joining the streams failed");
+            return rc2;
+        } else {
+            return fail(-1, "overlap needs the four-lane Riccati kernel (n <= 4)");
+        }
+    });
+}
 int ws_rollout(ilqr_ws* ws, int sub = -1)
 {
     return run_pass(ws, KID_ROLLOUT, 0, "k_rollout", [&](auto S, const KArgs& a, hipStream_t st) {
@@ -443,9 +500,15 @@ int ws_solve_chain(ilqr_ws* ws, int sub)
     if ((rc = ws_rollout(ws, sub))) return rc;                       // :162-164
     if (ws->split) {
         if ((rc = ws_linearize(ws, sub))) return rc;                 // A_t, B_t of the initial trajectory (:96-97)
+        const bool ov = ws->overlap && sub < 0;
         for (int it = 0; it < ws->d.n_iterations; ++it) {            // :170
-            if ((rc = ws_riccati(ws, it, sub))) return rc;           // :99-135, :173-179
+            // with overlap the recursion of iteration it > 0 was launched together with the accept of it - 1
+            if (!(ov && it > 0) && (rc = ws_riccati(ws, it, sub))) return rc;   // :99-135, :173-179
             if ((rc = ws_linesearch(ws, sub))) return rc;            // :180-202 (+ checkpoints)
+            if (ov && it + 1 < ws->d.n_iterations) {
+                if ((rc = ws_accept_riccati_overlapped(ws, it))) return rc;
+                continue;
+            }
             if ((rc = ws_accept_lin(ws, it, sub))) return rc;        // :194-207 in place, segments in parallel
             if (!ACCEPT_FUSES_LINEARIZE && (rc = ws_linearize(ws, sub))) return rc;   // A_t, B_t for the next pass
         }
@@ -469,6 +532,7 @@ int validate_desc(const ilqr_desc* d)
     const int w = d->n_alpha_parallel;
     if (w != 0 && (w < 1 || w > 64 || (w & (w - 1)) != 0)) return fail(-1, "n_alpha_parallel must be 0 or a power of two <= 64");
     if (d->n_streams < 0 || d->n_streams > 4) return fail(-1, "n_streams must be 0 (default: 1) to 4");
+    if (d->overlap < 0 || d->overlap > 2) return fail(-1, "overlap must be 0 (auto), 1 (off) or 2 (on whenever the horizon has two segments)");
     if (d->riccati < 0 || d->riccati > 3) return fail(-1, "riccati must be 0 (auto), 1 (lane per problem), 2 (16-lane group) or 3 (4-lane quad)");
     if (d->pipeline < 0 || d->pipeline > 2) return fail(-1, "pipeline must be 0 (auto), 1 (fused) or 2 (split)");
     if (!(d->learning_speed > 0.0 && d->learning_speed < 1.0)) return fail(-1, "learning_speed must be in (0,1)");
@@ -496,6 +560,7 @@ void ilqr_desc_default(ilqr_desc* d)
     d->quu_reg = 0.0;
     d->pipeline = 0;
     d->n_streams = 0;
+    d->overlap = 0;
     d->riccati = 0;
 }
 
@@ -637,8 +702,17 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
     // (every lane of a quad loads the whole record), hence up to 128 tiles; riccati = 3 forces it (n <= 4)
     ws->quad = !ws->grp && ws->n <= 4 && (d->riccati == 3 || (d->riccati == 0 && ws->n == 4 && ws->split && ws->tiles <= 128));
     if (ws->quad) ws->split = 1;
+    // accept of iteration i overlapped with the recursion of iteration i + 1 (ws_accept_riccati_overlapped): whenever
+    // the quad kernel runs the whole batch as one chain; overlap = 1 switches it off
+    ws->overlap = ws->quad && d->overlap != 1 && d->n_iterations > 1 && d->n_streams <= 1 && ACCEPT_FUSES_LINEARIZE;
     ws->ck = CKPT_INTERVAL;
     ws->n_seg = (ws->N + ws->ck - 1) / ws->ck;
+    // chunks of at least 4 segments (a smaller accept launch does not fill the chip), at most OVERLAP_CHUNKS; measured on
+    // the headline config: 3 chunks 69.5 ms per solve (worse than no overlap, 66.1), 4: 64.3, 6: 63.3, 10: 63.0
+    // overlap = 2 forces it with chunks of one segment or more (tests)
+    const int min_seg = d->overlap == 2 ? 1 : 4;
+    ws->n_chunks = ws->n_seg / min_seg < OVERLAP_CHUNKS ? ws->n_seg / min_seg : OVERLAP_CHUNKS;
+    if (ws->n_chunks < (d->overlap == 2 ? 2 : 4)) ws->overlap = 0;
     ws->n_lin = with_system(d->system_id, [&](auto S) { return Lin<decltype(S)>::n_lin; });
     const size_t Bp = (size_t)ws->Bpad, n = ws->n, m = ws->m, np = ws->np, N = ws->N;
     struct { void** p; size_t bytes; } allocs[] = {
@@ -653,6 +727,7 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
         {(void**)&ws->XB, ws->split ? Bp * (size_t)ws->n_seg * n * 8 : 0},
         {(void**)&ws->CKPT, ws->split ? Bp * (size_t)ws->n_seg * n * TILE * 8 : 0},
         {(void**)&ws->LIN, ws->split ? Bp * N * (size_t)ws->n_lin * 8 : 0},
+        {(void**)&ws->VST, ws->overlap ? Bp * (n * n + n + 4) * 8 : 0},
     };
     ws->hbm_bytes = 0;
     for (auto& al : allocs) {
@@ -678,6 +753,11 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
             HIPCHK(hipEventCreateWithFlags(&ws->sub_done[sb], hipEventDisableTiming));
         }
     }
+    if (ws->overlap) {
+        HIPCHK(hipStreamCreate(&ws->pipe_stream));
+        for (int c = 0; c < OVERLAP_CHUNKS; ++c) HIPCHK(hipEventCreateWithFlags(&ws->pipe_ev[c], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ws->pipe_done, hipEventDisableTiming));
+    }
     HIPCHK(hipMemcpy(ws->alphas, alphas, sizeof(alphas), hipMemcpyHostToDevice));
     HIPCHK(hipMemsetAsync(ws->WTS, 0, (2 * n * n + m * m) * 8, ws->stream));
     HIPCHK(hipMemsetAsync(ws->dJ, 0, 3 * Bp * 8, ws->stream));
@@ -702,7 +782,10 @@ int ilqr_ws_destroy(ilqr_ws* ws)
     (void)hipSetDevice(ws->d.device);
     if (ws->stream) (void)hipStreamSynchronize(ws->stream);
     for (auto& ev : ws->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    void* ptrs[] = {ws->XB, ws->CKPT, ws->LIN, ws->X, ws->U, ws->G, ws->KFB, ws->KFF, ws->XO, ws->UO, ws->INIT, ws->TARGET, ws->PARAMS, ws->WTS, ws->alphas,
+    if (ws->pipe_stream) { (void)hipStreamSynchronize(ws->pipe_stream); (void)hipStreamDestroy(ws->pipe_stream); }
+    for (int c = 0; c < OVERLAP_CHUNKS; ++c) if (ws->pipe_ev[c]) (void)hipEventDestroy(ws->pipe_ev[c]);
+    if (ws->pipe_done) (void)hipEventDestroy(ws->pipe_done);
+    void* ptrs[] = {ws->VST, ws->XB, ws->CKPT, ws->LIN, ws->X, ws->U, ws->G, ws->KFB, ws->KFF, ws->XO, ws->UO, ws->INIT, ws->TARGET, ws->PARAMS, ws->WTS, ws->alphas,
                     ws->alpha_pp, ws->cost, ws->new_cost, ws->dJ, ws->trace, ws->active, ws->iters, ws->status, ws->acc_j,
                     ws->ls_rounds, ws->accepts, ws->ls_list, ws->ls_count, ws->staging};
     for (void* p : ptrs) if (p) (void)hipFree(p);

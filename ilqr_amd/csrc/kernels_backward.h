@@ -314,6 +314,9 @@ __device__ __forceinline__ void static_for(F&& f)
 //   * the small quantities (Q_u, Q_uu, its inverse, k, K, Q_ux) are computed by every lane.
 // A workgroup is one wave = 16 problems; a tile is 4 workgroups.
 // ------------------------------------------------------------------------------------------------
+#ifndef RICCATI_QUAD_PRIO
+#define RICCATI_QUAD_PRIO 1
+#endif
 #ifndef RICCATI_QUAD_PREFETCH
 #define RICCATI_QUAD_PREFETCH 6
 #endif
@@ -346,8 +349,16 @@ __global__ void __launch_bounds__(64) k_riccati_quad(const KArgs a)
     const bool owner = (lane & 3) < n;
     const int bl = ((blockIdx.x & 3) << 4) + (lane >> 2);                              // problem within the tile
     const long long b = tile * TILE + bl;
-    const bool act = a.active[b] != 0;
+    // overlapped with the accept step of the previous iteration (a.piped): that step's seg-0 block has not yet retired the
+    // problems whose search ran out (acc_j < 0), so they are masked here the way their cleared `active` would
+    const bool act = a.active[b] != 0 && (!a.piped || a.acc_j[b] >= 0);
     if (__ballot(act) == 0ull) return;
+    const bool first_chunk = a.t_hi >= a.N, last_chunk = a.t_lo <= 0;
+#if RICCATI_QUAD_PRIO
+    // one wave per SIMD on the critical path, sharing the SIMD with the accept step's memory-bound waves: issue first
+    if (a.piped) __builtin_amdgcn_s_setprio(3);
+#endif
+    double* vst = a.VST + (size_t)tile * (n * n + n + 4) * TILE + bl;
     double target[n], Qk[n * n], Rk[m * m], QT[n * n], Vx[n], Vc[n], Qkc[n];
     load_col<n>(a.TARGET + (size_t)tile * n * TILE + bl, target);
     load_uniform<n * n>(a.WTS, Qk);
@@ -358,7 +369,7 @@ __global__ void __launch_bounds__(64) k_riccati_quad(const KArgs a)
     const double* Lp = a.LIN + (size_t)tile * a.N * NL * TILE + bl;
     double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + bl;
     double* kp = a.KFF + (size_t)tile * a.N * m * TILE + bl;
-    terminal_value<S>(Xp + (size_t)a.N * n * TILE, target, QT, Vx);
+    if (first_chunk) terminal_value<S>(Xp + (size_t)a.N * n * TILE, target, QT, Vx);
     // this lane's column of Q_T (= V_xx), of Q_k, and where its column of A_t sits in a LIN record
     int aoff[n];
     bool aisx[n];
@@ -382,6 +393,12 @@ __global__ void __launch_bounds__(64) k_riccati_quad(const KArgs a)
     constexpr auto row_all_x = [](int r) { bool v = true; for (int q = 0; q < n; ++q) v = v && S::a_kind(r * n + q) == 'x'; return v; };
     double ecr = 0.0, ecr_g = 0.0, ecr_h = 0.0;
     bool ok = true;
+    if (!first_chunk) {                                                                // the chunk above left off here
+#pragma unroll
+        for (int r = 0; r < n; ++r) { Vc[r] = vst[(size_t)(r * n + c) * TILE]; Vx[r] = vst[(size_t)(n * n + r) * TILE]; }
+        ecr = vst[(size_t)(n * n + n) * TILE]; ecr_g = vst[(size_t)(n * n + n + 1) * TILE]; ecr_h = vst[(size_t)(n * n + n + 2) * TILE];
+        ok = vst[(size_t)(n * n + n + 3) * TILE] != 0.0;
+    }
     constexpr int D = RICCATI_QUAD_PREFETCH;
     auto fetch = [&](const int tl, double (&A)[n * n], double (&Bm)[n * m], double (&u)[m], double (&Acr)[n]) {
         const double* l = Lp + (size_t)tl * NL * TILE;
@@ -535,23 +552,36 @@ __global__ void __launch_bounds__(64) k_riccati_quad(const KArgs a)
     };
     // the first N mod D steps one by one, then whole groups of D steps from a ring of D slots (the group loop has no
     // exit inside its unrolled body: an early exit there costs a register shuffle per step)
-    int t0 = a.N - 1;
-    for (const int rem = a.N % D; t0 >= a.N - rem; --t0) {
+    int t0 = a.t_hi - 1;
+    for (const int rem = (a.t_hi - a.t_lo) % D; t0 >= a.t_hi - rem; --t0) {
         double A1[n * n], B1[n * m], u1[m], Ac1[n];
         fetch(t0, A1, B1, u1, Ac1);
         one_step(t0, A1, B1, u1, Ac1, [] {});
     }
     double Ar[D][n * n], Br[D][n * m], ur[D][m], Ac[D][n];
-    if (t0 >= 0) {
+    if (t0 >= a.t_lo) {
 #pragma unroll
         for (int d = 0; d < D; ++d) fetch(t0 - d, Ar[d], Br[d], ur[d], Ac[d]);
     }
-    for (; t0 >= 0; t0 -= D) {                                                         // :82
+    for (; t0 >= a.t_lo; t0 -= D) {                                                    // :82
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int t = t0 - d;
-            one_step(t, Ar[d], Br[d], ur[d], Ac[d], [&] { fetch(t - D > 0 ? t - D : 0, Ar[d], Br[d], ur[d], Ac[d]); });
+            one_step(t, Ar[d], Br[d], ur[d], Ac[d], [&] { fetch(t - D > a.t_lo ? t - D : a.t_lo, Ar[d], Br[d], ur[d], Ac[d]); });
         }
+    }
+    if (!last_chunk) {                                                                 // hand over to the chunk below
+        if (owner) {
+#pragma unroll
+            for (int r = 0; r < n; ++r) vst[(size_t)(r * n + c) * TILE] = Vc[r];
+        }
+        if ((lane & 3) == 0) {
+#pragma unroll
+            for (int r = 0; r < n; ++r) vst[(size_t)(n * n + r) * TILE] = Vx[r];
+            vst[(size_t)(n * n + n) * TILE] = ecr; vst[(size_t)(n * n + n + 1) * TILE] = ecr_g; vst[(size_t)(n * n + n + 2) * TILE] = ecr_h;
+            vst[(size_t)(n * n + n + 3) * TILE] = ok ? 1.0 : 0.0;
+        }
+        return;
     }
     if (act && (lane & 3) == 0) backward_epilogue(a, tile, bl, b, ecr, ecr_g, ecr_h, ok);
 }

@@ -82,6 +82,10 @@ struct KArgs {
     int ls_last;           // no round follows: a search that fails here has run out of learning rate
     int* ls_list;          // [2][Bpad] problems still searching after a round (ping-pong by round parity)
     int* ls_count;         // [MAX_TRIALS] length of the list each round leaves (zeroed before round 0)
+    // overlapped accept / Riccati (ilqr_desc.overlap): k_accept_lin covers segments [seg_lo, seg_lo + seg_cnt), k_riccati_quad
+    // steps [t_lo, t_hi) with the value function handed from chunk to chunk through VST
+    int seg_lo, seg_cnt, t_lo, t_hi, piped;
+    double* VST;           // [tile][n*n + n + 4][TILE]: V_xx, V_x, the three expected-reduction sums, ok
     int* accepts;
     double* trace;         // [tile][n_iter][6][64] or nullptr
     long long Bpad;

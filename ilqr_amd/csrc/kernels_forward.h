@@ -519,8 +519,8 @@ template <class S>
 __global__ void __launch_bounds__(64) k_accept_lin(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
-    const long long tile = a.tile0 + blockIdx.x / a.n_seg;
-    const int seg = (int)(blockIdx.x % a.n_seg);
+    const long long tile = a.tile0 + blockIdx.x / a.seg_cnt;                           // grid = tiles x seg_cnt
+    const int seg = a.seg_lo + (int)(blockIdx.x % a.seg_cnt);
     const int lane = threadIdx.x;
     const long long b = tile * TILE + lane;
     const bool act = a.active[b] != 0;

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ILQR_ABI_VERSION 4
+#define ILQR_ABI_VERSION 5
 
 /* systems compiled into the library (sympy-generated __device__ dynamics, ilqr_amd/csrc/dynamics/) */
 enum { ILQR_SYS_PENDULUM = 0, ILQR_SYS_ACROBOT = 1, ILQR_SYS_CARTPOLE = 2, ILQR_SYS_QUADCOPTER = 3, ILQR_SYS_CAR = 4,
@@ -67,6 +67,11 @@ typedef struct ilqr_desc {
                                      per problem for n = 4 in split-pipeline batches of up to 8192 problems; larger n: a row
                                      of 16 lanes), 1 lane, 2 row of 16 lanes, 3 four lanes (n <= 4).  2 and 3 imply
                                      pipeline 2.  1 and 3 give bit-identical results. */
+    int32_t overlap;              /* solve() with the four-lane recursion: the accept step of iteration i (parallel over
+                                     segments of the horizon, last segments first) and the backward recursion of
+                                     iteration i + 1 (which walks the horizon from its end) run overlapped on two HIP
+                                     streams, in chunks.  0 auto (on when the horizon gives at least 4 chunks of 4 segments of
+                                     64 steps), 1 off, 2 on from two segments up.  Results do not depend on it. */
 } ilqr_desc;
 
 void ilqr_desc_default(ilqr_desc* d);

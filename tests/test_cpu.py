@@ -175,7 +175,7 @@ def test_library_exports_every_declared_symbol():
     for nme in names:
         assert hasattr(handle, nme), nme
     assert sorted(_lib.SIGNATURES) == names      # the python binding covers the header exactly
-    assert _lib.lib().ilqr_abi_version() == 4
+    assert _lib.lib().ilqr_abi_version() == 5
 
 
 def test_library_host_side_calls_without_gpu():

@@ -308,6 +308,31 @@ def test_quad_riccati_is_bitwise_the_lane_riccati(amd, system):
         assert np.array_equal(a, b, equal_nan=True)
 
 
+@pytest.mark.parametrize('system,N', [('acrobot', 130), ('acrobot', 1100), ('cartpole', 333), ('car', 64), ('pendulum', 7)])
+def test_overlapped_accept_and_riccati_change_nothing(amd, system, N):
+    """solve() with the accept step of iteration i and the recursion of iteration i + 1 overlapped on two streams (chunks
+    of the horizon, value function handed on through memory) against the plain sequence of launches: every output
+    bit-identical, including problems whose search runs out or that stop as optimal part-way (their gains must stay
+    those of their last backward pass).  Horizons shorter than, equal to and not a multiple of the chunking."""
+    from ilqr_amd import _lib
+    g, init, guess = random_batch(system, 70, N, seed=11)
+    outs = []
+    for overlap in (1, 2):
+        ws = amd.Workspace(system, N, 70, float(g['dt']), want_trace=True, n_iterations=6, pipeline=2, riccati=3, overlap=overlap)
+        ws.set_weights(g['Qk'], g['Rk'], g['QT'])
+        for f, a in ((_lib.F_PARAMS, g['params']), (_lib.F_INIT, init), (_lib.F_TARGET, g['target']), (_lib.F_GUESS, guess)):
+            ws.upload(f, a)
+        ws.solve()
+        ws.sync()
+        outs.append([ws.download(f) for f in (_lib.F_STATES, _lib.F_INPUTS, _lib.F_KFB, _lib.F_KFF, _lib.F_COST, _lib.F_DJ,
+                                              _lib.F_STATUS, _lib.F_ITERS, _lib.F_TRACE)])
+        ws.solve()                                              # a second solve on the same workspace (state handed over cleanly)
+        ws.sync()
+        assert np.array_equal(ws.download(_lib.F_KFB), outs[-1][2], equal_nan=True)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 @pytest.mark.parametrize('pipeline', [1, 2])
 def test_sub_batches_on_streams_do_not_change_results(amd, pipeline):
     """solve() split into 3 independent sub-batches (uneven tile ranges: 200 problems = 4 tiles) on 3 HIP streams"""
