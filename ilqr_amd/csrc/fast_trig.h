@@ -93,14 +93,21 @@ __device__ __forceinline__ void ilqr_sincos_sum(const double a, const double b, 
     c_out = __builtin_fma(S, e, C);
 }
 
-// 1/d for the shared-reciprocal division below: hardware estimate + two Newton steps (what the compiler's own fp64
-// division does, minus its rescaling and special-case fix-up: 5 instructions instead of 11).  Within half an ulp of
-// 1/d in all but rare cases; d = 0 gives NaN (the IEEE quotient a/0 is inf or NaN: the trajectory is lost either way).
+// 1/d for the shared-reciprocal division below: hardware estimate + ILQR_RCP_NEWTON Newton steps (what the compiler's own
+// fp64 division does, minus its rescaling and special-case fix-up: 5 instructions instead of 11).  With two steps the
+// reciprocal is within half an ulp in all but rare cases.  One step would do for the quotient (ilqr_div_shared's
+// residual correction is itself a Newton step; tools/trig_accuracy.cpp finds no quotient that differs from IEEE) and
+// saves 2 instructions per divisor, +0.8 % on the headline -- measured and left at two: the few differently rounded
+// quotients moved the quadcopter's 21-iteration K from 8.6e-9 to 9.2e-9 of the reference, too close to the 1e-8 bar.
+// d = 0 gives NaN (the IEEE quotient a/0 is inf or NaN: the trajectory is lost either way).
+#ifndef ILQR_RCP_NEWTON
+#define ILQR_RCP_NEWTON 2
+#endif
 __device__ __forceinline__ double ilqr_rcp(const double d)
 {
     double r = __builtin_amdgcn_rcp(d);
-    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
-    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+#pragma unroll
+    for (int i = 0; i < ILQR_RCP_NEWTON; ++i) r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
     return r;
 }
 
