@@ -89,7 +89,10 @@ int fail(int code, const char* fmt, ...)
 
 enum { KID_ROLLOUT = 0, KID_BACKWARD = 1, KID_LINESEARCH = 2, KID_ACCEPT = 3, KID_LTVLQR = 4, KID_FORWARD = 5, KID_COST = 6,
        KID_LINEARIZE = 7 };
-constexpr int CKPT_INTERVAL = 64;   // time steps between line-search checkpoints (split pipeline)
+#ifndef ILQR_CKPT_INTERVAL
+#define ILQR_CKPT_INTERVAL 64
+#endif
+constexpr int CKPT_INTERVAL = ILQR_CKPT_INTERVAL;   // time steps between line-search checkpoints (split pipeline)
 
 }  // namespace
 
