@@ -31,3 +31,7 @@ ran = np.isfinite(tr[:, :, 1]).sum()
 need = np.where(tr[:, :, 4] >= 0, tr[:, :, 4] + 1, info['n_trials'])[np.isfinite(tr[:, :, 1])].sum()
 print('rounds per search %.2f, trials needed by the sequential search %.1f' % (rounds.sum() / ran, need / ran))
 print('status counts', np.bincount(st, minlength=4), 'mean iterations', it.mean())
+# histogram of the trials each search needed (accepted j + 1; n_trials when it ran out): what a round schedule is sized on
+needed = np.where(tr[:, :, 4] >= 0, tr[:, :, 4] + 1, info['n_trials'])[np.isfinite(tr[:, :, 1])].astype(int)
+edges = [1, 2, 3, 5, 9, 17, 25, 33, 41, 49, 60]
+print('trials needed: ' + '  '.join('%d-%d: %.3f' % (lo, hi - 1, np.mean((needed >= lo) & (needed < hi))) for lo, hi in zip(edges[:-1], edges[1:])))
