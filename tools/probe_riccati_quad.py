@@ -18,6 +18,7 @@ for riccati in (1, 3, 0):
     t = time.perf_counter(); ws.solve(); ws.sync(); dt = time.perf_counter() - t
     prof = ws.profile_read()
     ms, cnt = prof['backward']
-    print('riccati=%d: solve %.1f ms (profiled)  backward %.3f ms/launch (%d)  cost[0]=%.12g' % (riccati, dt * 1e3, ms / max(cnt, 1), cnt, ws.download(_lib.F_COST)[0]))
+    ams, acnt = prof['accept']
+    print('riccati=%d: solve %.1f ms (profiled)  backward %.3f ms/launch (%d)  accept %.3f ms  cost[0]=%.12g' % (riccati, dt * 1e3, ms / max(cnt, 1), cnt, ams / max(acnt, 1), ws.download(_lib.F_COST)[0]))
     ws.profile(False)
     ws.close()
