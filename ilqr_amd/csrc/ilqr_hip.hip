@@ -3,10 +3,12 @@
 // What is here (reference = Kongx231/ilqr, python/ilqr.py and python/ltvlqr.py):
 //   kernels_common.h    systems, kernel arguments, the per-step Riccati algebra (ilqr.py:84-125)
 //   kernels_backward.h  k_backward (ilqr.backwards_pass, ilqr.py:64-135 + the "optimal" stop test :175), the split
-//                       schedule's k_linearize / k_riccati / k_riccati_grp, k_ltvlqr (ltvlqr.py:3-28)
+//                       schedule's k_linearize / k_riccati / k_riccati_quad (4 lanes per problem) / k_riccati_grp (16 lanes,
+//                       also the n = 12 ltvlqr), k_ltvlqr (ltvlqr.py:3-28)
 //   kernels_forward.h   k_rollout (ilqr.rollout :30-47 + compute_cost :49-62), k_cost, k_linesearch (the while loop of
 //                       solve, :180-202: W trials per problem on W adjacent lanes, one launch per round, first accepted
-//                       trial by ballot), k_forward (forwards_pass :137-158 and the fused accept :194-199), k_accept_lin
+//                       trial by ballot), k_ls_compact, k_forward (forwards_pass :137-158 and the fused accept :194-199),
+//                       k_accept_lin
 //   kernels_util.h      k_dynamics (the lambdified f/A/B, symbolic_dynamics.py:23-25,88-90), k_pack / k_unpack
 //                       (reference layout (B,T,C) <-> tiled SoA [b/64][T][C][b%64])
 //   this file           the workspace (device-resident batch), the pass schedule of solve(), the C ABI (include/ilqr_hip.h)
