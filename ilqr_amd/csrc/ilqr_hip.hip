@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -691,6 +692,18 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
             if (widen && w > 16) w = 16;
             ws->ls_width[ws->ls_rounds_n++] = w;
             covered += w;
+        }
+        // development aid: ILQR_LS_SCHEDULE="4,4,8,16,32" replaces the widths (powers of two <= 64; the last one repeats)
+        if (const char* env = getenv("ILQR_LS_SCHEDULE")) {
+            int n_r = 0, cov = 0, last = 0;
+            const char* q = env;
+            while (cov < n_trials && n_r < MAX_TRIALS) {
+                int w = last;
+                if (*q) { w = atoi(q); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+                if (w < 1 || w > 64 || (w & (w - 1)) != 0) { n_r = 0; break; }
+                ws->ls_width[n_r++] = w; cov += w; last = w;
+            }
+            if (n_r > 0 && cov >= n_trials) ws->ls_rounds_n = n_r;
         }
     }
     // pipeline: with few tiles the horizon-sequential kernels occupy one wave per tile and leave most of the 1024 SIMDs
