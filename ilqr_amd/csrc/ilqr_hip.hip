@@ -40,7 +40,10 @@
 #define ILQR_DYN_SINCOS(x, s, c) ilqr_sincos_fast((x), (s), (c))
 #define ILQR_DYN_SINCOS_SLOW(x, s, c) do { const ilqr_sc sc_ = ilqr_sincos_slow(x); (s) = sc_.sinv; (c) = sc_.cosv; } while (0)
 #define ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c) ilqr_sincos_sum((a), (b), (sa), (ca), (sb), (cb), (s), (c))
-#define ILQR_DYN_TRIG_BIG(x) (!(__builtin_fabs(x) < 1.0e6))
+// ordered compare: a NaN angle is NOT "big" -- the fast path turns NaN into NaN just as well, and a diverged trial of the
+// line search (NaN state for the rest of its horizon) would otherwise drag its whole wave through the library path at
+// every step (131 072 cartpoles: 221 -> 209 ms per solve).  Inf counts as big (one step later it is NaN).
+#define ILQR_DYN_TRIG_BIG(x) (__builtin_fabs(x) >= 1.0e6)
 // Fused multiply-adds inside the generated f (and only there).  Off: measured on the headline config it removes 15 % of the
 // line search's instructions but only 3.6 % of its time (4.96 -> 4.78 ms), and it breaks exact cancellations the reference
 // has (the quadcopter's hover rollout stays exactly 0 unfused, drifts to 1e-17 fused).  FMAs only where written.
