@@ -102,6 +102,9 @@ constexpr int CKPT_INTERVAL = ILQR_CKPT_INTERVAL;   // time steps between line-s
 
 }  // namespace
 
+#ifndef ILQR_OVERLAP_GEOMETRIC
+#define ILQR_OVERLAP_GEOMETRIC 0
+#endif
 #ifndef ILQR_OVERLAP_CHUNKS
 #define ILQR_OVERLAP_CHUNKS 10
 #endif
@@ -419,7 +422,16 @@ int ws_accept_riccati_overlapped(ilqr_ws* ws, int it)
                 std::unique_ptr<ProfScope> pb;
                 const int C = ws->n_chunks;
                 for (int c = C - 1; c >= 0 && !rc2; --c) {
+#if ILQR_OVERLAP_GEOMETRIC
+                    // chunk sizes growing from the end of the horizon (the first accept chunk is the exposed one, the later
+                    // ones fill the chip better): boundary of chunk c = n_seg * (1 - ((C - c) / C)^2).  Measured and left
+                    // off: the accept finishes sooner but the recursion, which is the critical path, is slowed more while
+                    // it lasts (63.4 vs 62.1 ms per solve with 10 chunks; 16 and 24 uniform chunks: 65.5 and 73.0)
+                    auto bound = [&](int cc) { const double f = (double)(C - cc) / C; return (int)(ws->n_seg * (1.0 - f * f) + 0.5); };
+                    const int s_lo = bound(c), s_hi = c + 1 == C ? ws->n_seg : bound(c + 1);
+#else
                     const int s_lo = (int)((long long)ws->n_seg * c / C), s_hi = (int)((long long)ws->n_seg * (c + 1) / C);
+#endif
                     if (s_hi <= s_lo) continue;
                     aa.seg_lo = s_lo; aa.seg_cnt = s_hi - s_lo;
                     hipLaunchKernelGGL(k_accept_lin<T>, dim3((unsigned)(aa.n_tiles * aa.seg_cnt)), dim3(64), 0, A, aa);
