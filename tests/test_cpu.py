@@ -212,6 +212,21 @@ def test_dropin_rejects_foreign_callables_and_bad_shapes():
 
 
 # ------------------------------------------------------------------------------------------ sharding (N > 1 path)
+def test_device_trig_and_division_accuracy_on_the_host(tmp_path):
+    """fast_trig.h (the sin/cos pair, the angle-addition pair and the shared-reciprocal division the generated dynamics use
+    on the GPU) compiled for the host with -ffp-contract=off and measured against 80-bit sinl/cosl by
+    tools/trig_accuracy.cpp: the accuracy DESIGN.md states is what the header delivers."""
+    import re, subprocess
+    exe = str(tmp_path / 'trig_accuracy')
+    subprocess.check_call(['g++', '-O2', '-ffp-contract=off', '-o', exe, os.path.join(ROOT, 'tools', 'trig_accuracy.cpp'), '-lm'])
+    out = subprocess.check_output([exe, '400000'], text=True)
+    errs = [float(v) for v in re.findall(r'(?:sin|cos) ([0-9.]+) ulp', out)]
+    assert len(errs) == 12 and max(errs) < 0.85, out                         # 5 ranges + near multiples of pi/2, sin and cos
+    assert float(re.search(r'sincos_sum\s+max abs err ([0-9.e+-]+)', out).group(1)) < 5e-16, out
+    m = re.search(r'shared division max err ([0-9.]+) ulp, differs from IEEE in ([0-9.]+) %', out)
+    assert float(m.group(1)) <= 0.5 and float(m.group(2)) < 0.01, out
+
+
 def test_shard_ranges_cover_the_batch():
     from ilqr_amd.sharding import shard_range
     for batch, world in ((4096, 8), (10, 4), (3, 8), (1 << 20, 8), (262144, 8)):
