@@ -62,10 +62,37 @@
 #include "dynamics/pendulum.h"
 #include "dynamics/acrobot.h"
 #include "dynamics/cartpole.h"
-#include "dynamics/quadcopter.h"
 #include "dynamics/car.h"
 #include "dynamics/double_integrator.h"
 #include "dynamics/double_pendulum.h"
+// The quadcopter comes last: its dynamics use the LIBRARY's sin/cos/tan.  Its 21-iteration example solve amplifies
+// last-bit rounding most: with the fast pair above (0.79 ulp) the final K is 9.2e-9 from the
+// reference, with ocml's (as accurate as the glibc the reference runs on) 3.8e-9 -- a 2.6x margin to the 1e-8 bar for
+// 10 % of that system's speed (32 768 problems: 180 -> 200 ms per solve).  IEEE divisions instead of the shared
+// reciprocal change nothing (same digits) and stay off.
+#ifndef ILQR_QUAD_TRIG_LIB
+#define ILQR_QUAD_TRIG_LIB 1
+#endif
+#ifndef ILQR_QUAD_DIV_IEEE
+#define ILQR_QUAD_DIV_IEEE 0
+#endif
+#if ILQR_QUAD_TRIG_LIB
+#undef ILQR_DYN_SINCOS
+#undef ILQR_DYN_SINCOS_SUM
+#undef ILQR_DYN_TRIG_BIG
+#undef ILQR_DYN_TAN_SC
+#define ILQR_DYN_SINCOS(x, s, c) do { (s) = sin(x); (c) = cos(x); } while (0)
+#define ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c) do { (s) = sin((a) + (b)); (c) = cos((a) + (b)); } while (0)
+#define ILQR_DYN_TRIG_BIG(x) 0
+#define ILQR_DYN_TAN_SC(x, s, c) tan(x)
+#endif
+#if ILQR_QUAD_DIV_IEEE
+#undef ILQR_DYN_RCP
+#undef ILQR_DYN_DIV
+#define ILQR_DYN_RCP(d) 0.0
+#define ILQR_DYN_DIV(a, d, rd) ((a) / (d))
+#endif
+#include "dynamics/quadcopter.h"
 
 namespace {
 
