@@ -308,7 +308,7 @@ def test_quad_riccati_is_bitwise_the_lane_riccati(amd, system):
         assert np.array_equal(a, b, equal_nan=True)
 
 
-@pytest.mark.parametrize('system,N', [('acrobot', 130), ('acrobot', 1100), ('cartpole', 333), ('car', 64), ('pendulum', 7)])
+@pytest.mark.parametrize('system,N', [('acrobot', 130), ('acrobot', 1100), ('cartpole', 333), ('car', 200), ('double_pendulum', 150), ('car', 64), ('pendulum', 7)])
 def test_overlapped_accept_and_riccati_change_nothing(amd, system, N):
     """solve() with the accept step of iteration i and the recursion of iteration i + 1 overlapped on two streams (chunks
     of the horizon, value function handed on through memory) against the plain sequence of launches: every output
