@@ -169,6 +169,11 @@ def _pattern(mat):
     return ''.join(out)
 
 
+def _dt_mask(mat, dt):
+    """'1' where the entry is exactly the step dt (a uniform constant the solver need not store per time step), else '0'."""
+    return ''.join('1' if mat[i, j] == dt else '0' for i in range(mat.shape[0]) for j in range(mat.shape[1]))
+
+
 def _function(model, what, mat):
     args = (model.states, model.inputs, model.dt, model.parameters)
     src = inspect.getsource(sp.lambdify(args, mat))
@@ -246,6 +251,9 @@ def generate(name):
     parts.append('/* sparsity of the Jacobians: \'0\' structural zero, \'1\' structural one, \'x\' general */')
     parts.append('ILQR_DYN_CONST char ilqr_dyn_%s_A_pat[%d] = "%s";' % (name, n * n + 1, _pattern(model.A_disc)))
     parts.append('ILQR_DYN_CONST char ilqr_dyn_%s_B_pat[%d] = "%s";' % (name, n * m + 1, _pattern(model.B_disc)))
+    parts.append('/* entries that are exactly dt (general for the algebra, but uniform: not stored per step) */')
+    parts.append('ILQR_DYN_CONST char ilqr_dyn_%s_A_dt[%d] = "%s";' % (name, n * n + 1, _dt_mask(model.A_disc, model.dt)))
+    parts.append('ILQR_DYN_CONST char ilqr_dyn_%s_B_dt[%d] = "%s";' % (name, n * m + 1, _dt_mask(model.B_disc, model.dt)))
     srcs = {}
     for what, mat in (('f', model.f_disc), ('A', model.A_disc), ('B', model.B_disc)):
         code, src = _function(model, what, mat)

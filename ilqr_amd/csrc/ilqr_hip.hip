@@ -470,7 +470,7 @@ int ws_accept_riccati_overlapped(ilqr_ws* ws, int it)
                     if (!pb) pb.reset(new ProfScope(ws, KID_BACKWARD, B));
                     ar.t_lo = s_lo * ws->ck;
                     ar.t_hi = s_hi * ws->ck < ws->N ? s_hi * ws->ck : ws->N;
-                    hipLaunchKernelGGL(k_riccati_quad<T>, dim3((unsigned)(ar.n_tiles * 4)), dim3(64), 0, B, ar);
+                    hipLaunchKernelGGL((k_riccati_quad<T, true>), dim3((unsigned)(ar.n_tiles * 4)), dim3(64), 0, B, ar);
                     rc2 = check_launch("k_riccati_quad");
                 }
             }   // the accept scope closes on A here; pb closed on B when it went out of scope above

@@ -91,14 +91,11 @@ __global__ void __launch_bounds__(64) k_backward(const KArgs a)
 
 template <class S>
 struct Lin {
-    static constexpr int count_x(const char* pat, int len)
-    {
-        int c = 0;
-        for (int i = 0; i < len; ++i) c += pat[i] == 'x';
-        return c;
-    }
-    static constexpr int nA = count_x(S::A_pat, S::n * S::n);
-    static constexpr int nB = count_x(S::B_pat, S::n * S::m);
+    // stored per step: the general entries of A_t, B_t except those that are exactly dt (uniform; S::a_stored)
+    static constexpr int count_a() { int c = 0; for (int i = 0; i < S::n * S::n; ++i) c += S::a_stored(i); return c; }
+    static constexpr int count_b() { int c = 0; for (int i = 0; i < S::n * S::m; ++i) c += S::b_stored(i); return c; }
+    static constexpr int nA = count_a();
+    static constexpr int nB = count_b();
     static constexpr int n_lin = nA + nB;
 };
 
@@ -111,9 +108,9 @@ __device__ __forceinline__ void store_lin(double* l, const double (&A)[S::n * S:
     constexpr int n = S::n, m = S::m;
     int e = 0;
 #pragma unroll
-    for (int i = 0; i < n * n; ++i) if (S::a_kind(i) == 'x') { l[(size_t)e * TILE] = A[i]; ++e; }
+    for (int i = 0; i < n * n; ++i) if (S::a_stored(i)) { l[(size_t)e * TILE] = A[i]; ++e; }
 #pragma unroll
-    for (int i = 0; i < n * m; ++i) if (S::b_kind(i) == 'x') { l[(size_t)e * TILE] = Bm[i]; ++e; }
+    for (int i = 0; i < n * m; ++i) if (S::b_stored(i)) { l[(size_t)e * TILE] = Bm[i]; ++e; }
 }
 
 template <class S>
@@ -147,19 +144,19 @@ __global__ void __launch_bounds__(64) k_linearize(const KArgs a)
 }
 
 template <class S>
-__device__ __forceinline__ void load_lin(const double* l, double (&A)[S::n * S::n], double (&Bm)[S::n * S::m])
+__device__ __forceinline__ void load_lin(const double* l, double (&A)[S::n * S::n], double (&Bm)[S::n * S::m], const double dt)
 {
     constexpr int n = S::n, m = S::m;
     int e = 0;
 #pragma unroll
     for (int i = 0; i < n * n; ++i) {
         const char kd = S::a_kind(i);
-        if (kd == 'x') { A[i] = l[(size_t)e * TILE]; ++e; } else A[i] = kd == '1' ? 1.0 : 0.0;
+        if (S::a_stored(i)) { A[i] = l[(size_t)e * TILE]; ++e; } else A[i] = S::a_is_dt(i) ? dt : (kd == '1' ? 1.0 : 0.0);
     }
 #pragma unroll
     for (int i = 0; i < n * m; ++i) {
         const char kd = S::b_kind(i);
-        if (kd == 'x') { Bm[i] = l[(size_t)e * TILE]; ++e; } else Bm[i] = kd == '1' ? 1.0 : 0.0;
+        if (S::b_stored(i)) { Bm[i] = l[(size_t)e * TILE]; ++e; } else Bm[i] = S::b_is_dt(i) ? dt : (kd == '1' ? 1.0 : 0.0);
     }
 }
 
@@ -210,7 +207,7 @@ __global__ void __launch_bounds__(64) k_riccati(const KArgs a)
     int t0 = a.N - 1;
     for (const int rem = a.N % D; t0 >= a.N - rem; --t0) {
         double A1[n * n], B1[n * m], u1[m];
-        load_lin<S>(Lp + (size_t)t0 * Lin<S>::n_lin * TILE, A1, B1);
+        load_lin<S>(Lp + (size_t)t0 * Lin<S>::n_lin * TILE, A1, B1, a.dt);
         load_col<m>(Up + (size_t)t0 * m * TILE, u1);
         one_step(t0, A1, B1, u1, [] {});
     }
@@ -218,7 +215,7 @@ __global__ void __launch_bounds__(64) k_riccati(const KArgs a)
     if (t0 >= 0) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            load_lin<S>(Lp + (size_t)(t0 - d) * Lin<S>::n_lin * TILE, Ar[d], Br[d]);
+            load_lin<S>(Lp + (size_t)(t0 - d) * Lin<S>::n_lin * TILE, Ar[d], Br[d], a.dt);
             load_col<m>(Up + (size_t)(t0 - d) * m * TILE, ur[d]);
         }
     }
@@ -228,7 +225,7 @@ __global__ void __launch_bounds__(64) k_riccati(const KArgs a)
             const int t = t0 - d;
             one_step(t, Ar[d], Br[d], ur[d], [&] {
                 const int tl = t - D > 0 ? t - D : 0;                                  // slot d next holds step t - D
-                load_lin<S>(Lp + (size_t)tl * Lin<S>::n_lin * TILE, Ar[d], Br[d]);
+                load_lin<S>(Lp + (size_t)tl * Lin<S>::n_lin * TILE, Ar[d], Br[d], a.dt);
                 load_col<m>(Up + (size_t)tl * m * TILE, ur[d]);
             });
         }
@@ -262,7 +259,7 @@ struct Grp {
     static_assert(n <= GL, "k_riccati_grp: one lane per state");
 };
 
-// index of dense entry e of A (or B) in the step's LIN row; -1 structural zero, -2 structural one
+// index of dense entry e of A (or B) in the step's LIN row; -1 structural zero, -2 structural one, -3 exactly dt (not stored)
 template <class S, bool IS_B>
 __device__ __forceinline__ int lin_index(const int e)
 {
@@ -272,8 +269,9 @@ __device__ __forceinline__ int lin_index(const int e)
 #pragma unroll
     for (int q = 0; q < cnt_all; ++q) {
         const char kd = IS_B ? S::b_kind(q) : S::a_kind(q);
-        if (q == e) res = kd == 'x' ? cnt : (kd == '1' ? -2 : -1);
-        if (kd == 'x') ++cnt;
+        const bool st = IS_B ? S::b_stored(q) : S::a_stored(q);
+        if (q == e) res = st ? cnt : (kd == 'x' ? -3 : (kd == '1' ? -2 : -1));
+        if (st) ++cnt;
     }
     return res;
 }
@@ -338,7 +336,13 @@ __device__ __forceinline__ double dot_dense(const double (&a)[CNT], const double
     return s;
 }
 
-template <class S>
+// DEEP: the chunks that run alongside the accept step see several times the memory latency (its 3.4 TB/s of traffic
+// queue ahead of this kernel's loads): a ring of 10 steps instead of 6 -- slower alone (1.35 -> 1.41 ms, more register
+// traffic), faster where it is used (62.2 -> 60.5 ms per overlapped solve)
+#ifndef RICCATI_QUAD_PREFETCH_DEEP
+#define RICCATI_QUAD_PREFETCH_DEEP 10
+#endif
+template <class S, bool DEEP = false>
 __global__ void __launch_bounds__(64) k_riccati_quad(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, NL = Lin<S>::n_lin;
@@ -385,12 +389,12 @@ __global__ void __launch_bounds__(64) k_riccati_quad(const KArgs a)
                 const int li = lin_index<S, false>(r * n + q);
                 aisx[r] = li >= 0;
                 aoff[r] = li >= 0 ? li * TILE : 0;
-                acst[r] = li == -2 ? 1.0 : 0.0;
+                acst[r] = li == -2 ? 1.0 : (li == -3 ? a.dt : 0.0);
             }
     }
     // rows of A with at least one general entry (only those are loaded per lane) / with only general entries
-    constexpr auto row_any_x = [](int r) { bool v = false; for (int q = 0; q < n; ++q) v = v || S::a_kind(r * n + q) == 'x'; return v; };
-    constexpr auto row_all_x = [](int r) { bool v = true; for (int q = 0; q < n; ++q) v = v && S::a_kind(r * n + q) == 'x'; return v; };
+    constexpr auto row_any_x = [](int r) { bool v = false; for (int q = 0; q < n; ++q) v = v || S::a_stored(r * n + q); return v; };
+    constexpr auto row_all_x = [](int r) { bool v = true; for (int q = 0; q < n; ++q) v = v && S::a_stored(r * n + q); return v; };
     double ecr = 0.0, ecr_g = 0.0, ecr_h = 0.0;
     bool ok = true;
     if (!first_chunk) {                                                                // the chunk above left off here
@@ -399,10 +403,10 @@ __global__ void __launch_bounds__(64) k_riccati_quad(const KArgs a)
         ecr = vst[(size_t)(n * n + n) * TILE]; ecr_g = vst[(size_t)(n * n + n + 1) * TILE]; ecr_h = vst[(size_t)(n * n + n + 2) * TILE];
         ok = vst[(size_t)(n * n + n + 3) * TILE] != 0.0;
     }
-    constexpr int D = RICCATI_QUAD_PREFETCH;
+    constexpr int D = DEEP ? RICCATI_QUAD_PREFETCH_DEEP : RICCATI_QUAD_PREFETCH;
     auto fetch = [&](const int tl, double (&A)[n * n], double (&Bm)[n * m], double (&u)[m], double (&Acr)[n]) {
         const double* l = Lp + (size_t)tl * NL * TILE;
-        load_lin<S>(l, A, Bm);
+        load_lin<S>(l, A, Bm, a.dt);
         load_col<m>(Up + (size_t)tl * m * TILE, u);
 #pragma unroll
         for (int r = 0; r < n; ++r) Acr[r] = row_any_x(r) ? l[aoff[r]] : 0.0;
@@ -611,19 +615,24 @@ __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KAr
     // where row cc of A_t / B_t sits in a LIN record: byte offsets of the general entries (structural zeros and ones
     // load a harmless valid entry instead; their constants are written to the transpose buffer once, below)
     int aoff[n], boff[m];
-    unsigned amask = 0;
+    unsigned amask = 0, adt = 0, bdt = 0;              // adt / bdt: entries of this lane's row that are exactly dt (not stored)
 #pragma unroll
     for (int i = 0; i < n; ++i) {
         const int q = lin_index<S, false>(cc * n + i);
         aoff[i] = (q > 0 ? q : 0) * (TILE * (int)sizeof(double));
         amask |= (q >= 0 ? 1u : 0u) << i;
-        if (row && q < 0) s[G::oAT + i * LD + c] = q == -2 ? 1.0 : 0.0;
+        adt |= (q == -3 ? 1u : 0u) << i;
+        if (row && q < 0) s[G::oAT + i * LD + c] = q == -2 ? 1.0 : (q == -3 ? a.dt : 0.0);
     }
 #pragma unroll
     for (int l = 0; l < m; ++l) {
         const int q = lin_index<S, true>(cc * m + l);
         boff[l] = (q > 0 ? q : 0) * (TILE * (int)sizeof(double));
+        bdt |= (q == -3 ? 1u : 0u) << l;
     }
+    // columns of A / B that hold a dt entry in some row (compile time): only those pay the per-lane patch below
+    constexpr auto a_col_dt = [](int i) { bool v = false; for (int r = 0; r < n; ++r) v = v || S::a_is_dt(r * n + i); return v; };
+    constexpr auto b_col_dt = [](int l) { bool v = false; for (int r = 0; r < n; ++r) v = v || S::b_is_dt(r * m + l); return v; };
     double Rk[m * m], Vc[n], vx;
     double* sQk = sh + P * G::SLOT;                                                    // Q_k, shared by the rows
     for (int e = lane; e < n * n; e += TILE) sQk[e] = a.WTS[e];
@@ -654,12 +663,14 @@ __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KAr
             int o = aoff[i];
             asm volatile("" : "+v"(o));                  // keep base + offset out of the loop-invariant (spilled) set
             Ar[i] = *(const double*)(l + o);
+            if (a_col_dt(i)) Ar[i] = ((adt >> i) & 1u) ? a.dt : Ar[i];
         }
 #pragma unroll
         for (int q = 0; q < m; ++q) {
             int o = boff[q];
             asm volatile("" : "+v"(o));
             Br[q] = *(const double*)(l + o);
+            if (b_col_dt(q)) Br[q] = ((bdt >> q) & 1u) ? a.dt : Br[q];
         }
 #pragma unroll
         for (int q = 0; q < m; ++q) u[q] = Up[((size_t)t * m + q) * TILE];

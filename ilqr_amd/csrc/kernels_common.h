@@ -9,6 +9,9 @@ constexpr int N_KERNEL_IDS = 8;
 // ------------------------------------------------------------------------------------------------
 // systems
 // ------------------------------------------------------------------------------------------------
+#ifndef ILQR_LIN_SKIP_DT
+#define ILQR_LIN_SKIP_DT 1
+#endif
 #define ILQR_DEFINE_SYSTEM(NAME, UP)                                                                              \
     struct Sys_##NAME {                                                                                           \
         static constexpr int n = ILQR_DYN_##UP##_N, m = ILQR_DYN_##UP##_M, np = ILQR_DYN_##UP##_NP;               \
@@ -17,6 +20,13 @@ constexpr int N_KERNEL_IDS = 8;
         static constexpr const char* B_pat = ilqr_dyn_##NAME##_B_pat;                                             \
         static __device__ __forceinline__ char a_kind(int i) { return ilqr_dyn_##NAME##_A_pat[i]; }               \
         static __device__ __forceinline__ char b_kind(int i) { return ilqr_dyn_##NAME##_B_pat[i]; }               \
+        /* general entries that are exactly dt are uniform: LIN does not store them (ILQR_LIN_SKIP_DT) */         \
+        static constexpr const char* A_dt = ilqr_dyn_##NAME##_A_dt;                                               \
+        static constexpr const char* B_dt = ilqr_dyn_##NAME##_B_dt;                                               \
+        static constexpr bool a_is_dt(int i) { return ILQR_LIN_SKIP_DT && ilqr_dyn_##NAME##_A_dt[i] == '1'; }     \
+        static constexpr bool b_is_dt(int i) { return ILQR_LIN_SKIP_DT && ilqr_dyn_##NAME##_B_dt[i] == '1'; }     \
+        static constexpr bool a_stored(int i) { return ilqr_dyn_##NAME##_A_pat[i] == 'x' && !a_is_dt(i); }        \
+        static constexpr bool b_stored(int i) { return ilqr_dyn_##NAME##_B_pat[i] == 'x' && !b_is_dt(i); }        \
         static __device__ __forceinline__ void f(const double* x, const double* u, double dt, const double* p,   \
                                                  double* o) { ilqr_dyn_##NAME##_f(x, u, dt, p, o); }              \
         static __device__ __forceinline__ void A(const double* x, const double* u, double dt, const double* p,   \
