@@ -23,6 +23,9 @@ F_INIT, F_TARGET, F_PARAMS, F_STATES, F_INPUTS, F_KFF, F_KFB, F_COST, F_DJ, F_IT
 KERNEL_NAMES = ('rollout', 'backward', 'linesearch', 'accept', 'ltvlqr', 'forward', 'cost', 'linearize')
 
 
+ERR_SINGULAR = -5      # ILQR_ERR_SINGULAR: np.linalg.inv would have raised LinAlgError
+
+
 class IlqrHipError(RuntimeError):
     pass
 
@@ -32,7 +35,8 @@ class Desc(C.Structure):
                 ('n_iterations', C.c_int32), ('n_alpha_parallel', C.c_int32), ('zero_first_state', C.c_int32),
                 ('device', C.c_int32), ('learning_speed', C.c_double), ('low_learning_rate', C.c_double),
                 ('low_expected_reduction', C.c_double), ('armijo_threshold', C.c_double), ('quu_reg', C.c_double),
-                ('target_batched', C.c_int32), ('params_batched', C.c_int32), ('pipeline', C.c_int32), ('n_streams', C.c_int32), ('riccati', C.c_int32), ('overlap', C.c_int32)]
+                ('target_batched', C.c_int32), ('params_batched', C.c_int32), ('pipeline', C.c_int32), ('n_streams', C.c_int32), ('riccati', C.c_int32), ('overlap', C.c_int32),
+                ('search_floor', C.c_double), ('n_devices', C.c_int32), ('device_wrap', C.c_int32)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -55,7 +59,7 @@ SIGNATURES = {
     'ilqr_backward_batched': (C.c_int, [_DESCP, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     'ilqr_forward_batched': (C.c_int, [_DESCP] + [_dp] * 13),
     'ilqr_solve_batched': (C.c_int, [_DESCP] + [_dp] * 12 + [_ip, _ip, _dp]),
-    'ltvlqr_batched': (C.c_int, [_DESCP, C.c_int32] + [_dp] * 7),
+    'ltvlqr_batched': (C.c_int, [_DESCP, C.c_int32] + [_dp] * 7 + [_ip]),
     'ilqr_ws_create': (C.c_int, [_DESCP, C.c_int32, C.POINTER(_WS)]),
     'ilqr_ws_destroy': (C.c_int, [_WS]),
     'ilqr_ws_set_weights': (C.c_int, [_WS, _dp, _dp, _dp]),
@@ -139,7 +143,8 @@ def system_dims(system):
 
 def make_desc(system, N, B, dt, n_iterations=0, n_alpha_parallel=0, zero_first_state=True, device=0,
               target_batched=False, params_batched=False, learning_speed=0.95, low_learning_rate=0.05,
-              low_expected_reduction=1e-3, armijo_threshold=0.1, quu_reg=0.0, pipeline=0, n_streams=0, riccati=0, overlap=0):
+              low_expected_reduction=1e-3, armijo_threshold=0.1, quu_reg=0.0, pipeline=0, n_streams=0, riccati=0, overlap=0,
+              search_floor=0.05, n_devices=0, device_wrap=False):
     d = Desc()
     lib().ilqr_desc_default(C.byref(d))
     d.system_id = SYSTEM_IDS[system] if isinstance(system, str) else int(system)
@@ -161,6 +166,9 @@ def make_desc(system, N, B, dt, n_iterations=0, n_alpha_parallel=0, zero_first_s
     d.n_streams = int(n_streams)
     d.riccati = int(riccati)
     d.overlap = int(overlap)
+    d.search_floor = float(search_floor)
+    d.n_devices = int(n_devices)
+    d.device_wrap = 1 if device_wrap else 0
     return d
 
 

@@ -28,6 +28,8 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -139,6 +141,7 @@ constexpr int OVERLAP_CHUNKS = ILQR_OVERLAP_CHUNKS;   // at most; a chunk is at 
 struct ilqr_ws {
     ilqr_desc d;
     int n, m, np, N, W, n_trials, want_trace;
+    double alpha_end;                        // the learning rate an exhausted line search ends with (ilqr.py:185,202)
     int ls_rounds_n, ls_width[MAX_TRIALS];   // line-search schedule: widths of the rounds (sum >= n_trials)
     long long B, Bpad, tiles;
     hipStream_t stream;
@@ -173,7 +176,7 @@ KArgs make_args(ilqr_ws* ws, int it)
     a.N = ws->N; a.it = it; a.n_iter = ws->d.n_iterations; a.zero_first = ws->d.zero_first_state;
     a.n_trials = ws->n_trials; a.state_rows = ws->state_rows; a.n_tiles = ws->tiles; a.tile0 = 0;
     a.dt = ws->d.dt; a.low_red = ws->d.low_expected_reduction; a.armijo_thr = ws->d.armijo_threshold;
-    a.quu_reg = ws->d.quu_reg;
+    a.quu_reg = ws->d.quu_reg; a.low_lr = ws->d.low_learning_rate; a.alpha_end = ws->alpha_end;
     a.XB = ws->XB; a.CKPT = ws->CKPT; a.LIN = ws->LIN; a.ck = ws->ck; a.n_seg = ws->n_seg;
     a.X = ws->X; a.U = ws->U; a.G = ws->G; a.KFB = ws->KFB; a.KFF = ws->KFF; a.XO = ws->X; a.UO = ws->U;
     a.INIT = ws->INIT; a.TARGET = ws->TARGET; a.PARAMS = ws->PARAMS; a.WTS = ws->WTS; a.alphas = ws->alphas;
@@ -583,10 +586,55 @@ int validate_desc(const ilqr_desc* d)
     if (d->overlap < 0 || d->overlap > 2) return fail(-1, "overlap must be 0 (auto), 1 (off) or 2 (on whenever the horizon has two segments)");
     if (d->riccati < 0 || d->riccati > 3) return fail(-1, "riccati must be 0 (auto), 1 (lane per problem), 2 (16-lane group) or 3 (4-lane quad)");
     if (d->pipeline < 0 || d->pipeline > 2) return fail(-1, "pipeline must be 0 (auto), 1 (fused) or 2 (split)");
+    if (d->device_wrap < 0 || d->device_wrap > 1) return fail(-1, "device_wrap must be 0 or 1");
     if (!(d->learning_speed > 0.0 && d->learning_speed < 1.0)) return fail(-1, "learning_speed must be in (0,1)");
     if (!(d->low_learning_rate > 0.0 && d->low_learning_rate < 1.0)) return fail(-1, "low_learning_rate must be in (0,1)");
+    if (!(d->search_floor > 0.0 && d->search_floor < 1.0)) return fail(-1, "search_floor must be in (0,1) (the reference's literal is 0.05)");
+    if (d->n_devices < 0 || d->n_devices > 64) return fail(-1, "n_devices must be 0 (one device) to 64");
     return 0;
 }
+
+// Multi-GPU form of the one-shot host entry points (ilqr_desc.n_devices = G > 1): the batch is cut into G contiguous
+// shards by problem index (sizes differ by at most one, remainder to the first shards -- ilqr_amd/sharding.py
+// shard_range is the same rule), shard r runs on device `device + r` on its own host thread and reads / writes its own
+// slice of the caller's arrays.  No term of ilqr.py / ltvlqr.py couples two problems: there is nothing to exchange.
+// fn(sub_descriptor, first_problem) runs one shard through the single-device path.
+template <class F>
+int run_sharded(const ilqr_desc* d, F&& fn)
+{
+    int rc = validate_desc(d);
+    if (rc) return rc;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(-1, "no HIP device visible");
+    const int G = d->n_devices;
+    if (!d->device_wrap && (d->device < 0 || d->device + G > ndev))
+        return fail(-1, "devices %d..%d requested, %d visible (device_wrap = 1 lets shards share a device)", d->device, d->device + G - 1, ndev);
+    const long long B = d->batch, base = B / G, rem = B % G;
+    std::vector<int> rcs(G, 0);
+    std::vector<std::string> errs(G);
+    std::vector<std::thread> threads;
+    threads.reserve(G);
+    for (int r = 0; r < G; ++r) {
+        const long long lo = r * base + (r < rem ? r : rem), cnt = base + (r < rem ? 1 : 0);
+        if (cnt == 0) continue;                          // more shards than problems
+        ilqr_desc sd = *d;
+        sd.n_devices = 1;
+        sd.batch = cnt;
+        sd.device = d->device_wrap ? (((d->device + r) % ndev) + ndev) % ndev : d->device + r;
+        threads.emplace_back([&, r, lo, sd] {
+            rcs[r] = fn(sd, lo);
+            if (rcs[r]) errs[r] = g_err;                 // g_err is per thread: hand the message to the caller's
+        });
+    }
+    for (auto& t : threads) t.join();
+    for (int r = 0; r < G; ++r)
+        if (rcs[r]) return fail(rcs[r], "shard %d of %d (device %d): %s", r, G, d->device + r, errs[r].c_str());
+    return 0;
+}
+// p + count elements, keeping an optional (null) argument null
+template <class T>
+T* shard_ptr(T* p, long long count) { return p ? p + count : nullptr; }
 
 }  // namespace
 
@@ -610,6 +658,9 @@ void ilqr_desc_default(ilqr_desc* d)
     d->n_streams = 0;
     d->overlap = 0;
     d->riccati = 0;
+    d->search_floor = 0.05;
+    d->n_devices = 0;
+    d->device_wrap = 0;
 }
 
 int ilqr_abi_version(void) { return ILQR_ABI_VERSION; }
@@ -654,23 +705,26 @@ int ilqr_dynamics_eval(int32_t sys, int32_t which, int64_t count, const double* 
     const int n = SYSTEMS[sys].n, m = SYSTEMS[sys].m, np = SYSTEMS[sys].np;
     const size_t osz = which == 0 ? n : (which == 1 ? n * n : n * m);
     double *dx = nullptr, *du = nullptr, *dp = nullptr, *dout = nullptr;
-    HIPCHK(hipMalloc((void**)&dx, count * n * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&du, count * m * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&dp, np * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&dout, count * osz * sizeof(double)));
-    HIPCHK(hipMemcpy(dx, x, count * n * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(du, u, count * m * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dp, params, np * sizeof(double), hipMemcpyHostToDevice));
-    const unsigned grid = (unsigned)((count + 63) / 64);
-    int rc = with_system(sys, [&](auto S) {
-        using T = decltype(S);
-        hipLaunchKernelGGL(k_dynamics<T>, dim3(grid), dim3(64), 0, 0, which, (long long)count, dx, du, dt, dp, dout);
-        return check_launch("k_dynamics");
-    });
-    if (rc == 0) {
-        hipError_t e = hipMemcpy(out, dout, count * osz * sizeof(double), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(-100 - (int)e, "hipMemcpy D2H: %s", hipGetErrorString(e));
-    }
+    // every exit frees the four buffers
+    auto run = [&]() -> int {
+        HIPCHK(hipMalloc((void**)&dx, count * n * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&du, count * m * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&dp, np * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&dout, count * osz * sizeof(double)));
+        HIPCHK(hipMemcpy(dx, x, count * n * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(du, u, count * m * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dp, params, np * sizeof(double), hipMemcpyHostToDevice));
+        const unsigned grid = (unsigned)((count + 63) / 64);
+        const int rc = with_system(sys, [&](auto S) {
+            using T = decltype(S);
+            hipLaunchKernelGGL(k_dynamics<T>, dim3(grid), dim3(64), 0, 0, which, (long long)count, dx, du, dt, dp, dout);
+            return check_launch("k_dynamics");
+        });
+        if (rc) return rc;
+        HIPCHK(hipMemcpy(out, dout, count * osz * sizeof(double), hipMemcpyDeviceToHost));
+        return 0;
+    };
+    const int rc = run();
     (void)hipFree(dx); (void)hipFree(du); (void)hipFree(dp); (void)hipFree(dout);
     return rc;
 }
@@ -696,20 +750,22 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
     ws->profiling = false;
     memset(ws->prof_ms, 0, sizeof(ws->prof_ms));
     memset(ws->prof_cnt, 0, sizeof(ws->prof_cnt));
-    // alpha table by repeated multiplication (ilqr.py:180,202) and the number of trials with alpha > low_lr (:185)
+    // alpha table by repeated multiplication (ilqr.py:180,202); the trials are those with alpha > the literal 0.05 of the
+    // while condition (:185, ilqr_desc.search_floor), and an exhausted search ends with the first alpha that is not
     double alphas[MAX_TRIALS];
     double lr = 1.0;
     int n_trials = 0;
     for (int j = 0; j < MAX_TRIALS; ++j) {
         alphas[j] = lr;
-        if (lr > d->low_learning_rate && n_trials == j) n_trials = j + 1;
+        if (lr > d->search_floor && n_trials == j) n_trials = j + 1;
         lr = d->learning_speed * lr;
     }
-    if (n_trials == MAX_TRIALS && lr > d->low_learning_rate) {
+    if (n_trials == MAX_TRIALS) {
         delete ws;
-        return fail(-1, "learning_speed/low_learning_rate need more than %d line-search trials", MAX_TRIALS);
+        return fail(-1, "learning_speed/search_floor need %d or more line-search trials (at most %d)", MAX_TRIALS, MAX_TRIALS - 1);
     }
     ws->n_trials = n_trials;
+    ws->alpha_end = alphas[n_trials];
     int W = d->n_alpha_parallel;
     if (W == 0) {   // auto: about two waves per SIMD (256 CUs x 4 SIMDs), 16 to 32 trials per problem and round.  The floor
         // is 16 even when the batch fills the chip many times over: every round is a full pass over the horizon, and with
@@ -801,38 +857,55 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
         }
         ws->hbm_bytes += al.bytes;
     }
-    hipError_t e = hipStreamCreate(&ws->stream);
-    if (e != hipSuccess) { ilqr_ws_destroy(ws); return fail(-100 - (int)e, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    // from here on a failure frees the workspace and everything it holds before returning (the caller never sees `ws`)
+#define WSCHK(expr)                                                                                    \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            const int c_ = fail(-100 - (int)e_, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            ilqr_ws_destroy(ws);                                                                       \
+            return c_;                                                                                 \
+        }                                                                                              \
+    } while (0)
+    WSCHK(hipStreamCreate(&ws->stream));
     ws->n_sub = d->n_streams > 0 ? d->n_streams : 1;
     if (ws->n_sub > ws->tiles) ws->n_sub = (int)ws->tiles;
     for (int sb = 0; sb <= ws->n_sub; ++sb) ws->sub_tile0[sb] = ws->tiles * sb / ws->n_sub;
     if (ws->n_sub > 1) {
-        HIPCHK(hipEventCreateWithFlags(&ws->sub_start, hipEventDisableTiming));
+        WSCHK(hipEventCreateWithFlags(&ws->sub_start, hipEventDisableTiming));
         for (int sb = 0; sb < ws->n_sub; ++sb) {
-            HIPCHK(hipStreamCreate(&ws->sub_stream[sb]));
-            HIPCHK(hipEventCreateWithFlags(&ws->sub_done[sb], hipEventDisableTiming));
+            WSCHK(hipStreamCreate(&ws->sub_stream[sb]));
+            WSCHK(hipEventCreateWithFlags(&ws->sub_done[sb], hipEventDisableTiming));
         }
     }
     if (ws->overlap) {
-        HIPCHK(hipStreamCreate(&ws->pipe_stream));
-        for (int c = 0; c < OVERLAP_CHUNKS; ++c) HIPCHK(hipEventCreateWithFlags(&ws->pipe_ev[c], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ws->pipe_done, hipEventDisableTiming));
+        WSCHK(hipStreamCreate(&ws->pipe_stream));
+        for (int c = 0; c < OVERLAP_CHUNKS; ++c) WSCHK(hipEventCreateWithFlags(&ws->pipe_ev[c], hipEventDisableTiming));
+        WSCHK(hipEventCreateWithFlags(&ws->pipe_done, hipEventDisableTiming));
     }
-    HIPCHK(hipMemcpy(ws->alphas, alphas, sizeof(alphas), hipMemcpyHostToDevice));
-    HIPCHK(hipMemsetAsync(ws->WTS, 0, (2 * n * n + m * m) * 8, ws->stream));
-    HIPCHK(hipMemsetAsync(ws->dJ, 0, 3 * Bp * 8, ws->stream));
-    HIPCHK(hipMemsetAsync(ws->KFB, 0, Bp * N * m * n * 8, ws->stream));
-    HIPCHK(hipMemsetAsync(ws->KFF, 0, Bp * N * m * 8, ws->stream));
-    HIPCHK(hipMemsetAsync(ws->X, 0, Bp * (N + 1) * n * 8, ws->stream));
-    HIPCHK(hipMemsetAsync(ws->U, 0, Bp * N * m * 8, ws->stream));
-    HIPCHK(hipMemsetAsync(ws->G, 0, Bp * N * m * 8, ws->stream));
-    HIPCHK(hipMemsetAsync(ws->cost, 0, Bp * 8, ws->stream));
-    HIPCHK(hipMemsetAsync(ws->new_cost, 0, Bp * 8, ws->stream));
-    HIPCHK(hipMemsetAsync(ws->TARGET, 0, Bp * n * 8, ws->stream));
+    WSCHK(hipMemcpy(ws->alphas, alphas, sizeof(alphas), hipMemcpyHostToDevice));
+    WSCHK(hipMemsetAsync(ws->WTS, 0, (2 * n * n + m * m) * 8, ws->stream));
+    WSCHK(hipMemsetAsync(ws->dJ, 0, 3 * Bp * 8, ws->stream));
+    WSCHK(hipMemsetAsync(ws->KFB, 0, Bp * N * m * n * 8, ws->stream));
+    WSCHK(hipMemsetAsync(ws->KFF, 0, Bp * N * m * 8, ws->stream));
+    WSCHK(hipMemsetAsync(ws->X, 0, Bp * (N + 1) * n * 8, ws->stream));
+    WSCHK(hipMemsetAsync(ws->U, 0, Bp * N * m * 8, ws->stream));
+    WSCHK(hipMemsetAsync(ws->G, 0, Bp * N * m * 8, ws->stream));
+    WSCHK(hipMemsetAsync(ws->cost, 0, Bp * 8, ws->stream));
+    WSCHK(hipMemsetAsync(ws->new_cost, 0, Bp * 8, ws->stream));
+    WSCHK(hipMemsetAsync(ws->TARGET, 0, Bp * n * 8, ws->stream));
     *out = ws;
     rc = ilqr_ws_reset(ws);
     if (rc) { ilqr_ws_destroy(ws); *out = nullptr; return rc; }
-    HIPCHK(hipStreamSynchronize(ws->stream));
+    {
+        hipError_t e_ = hipStreamSynchronize(ws->stream);
+        if (e_ != hipSuccess) {
+            const int c_ = fail(-100 - (int)e_, "hipStreamSynchronize: %s", hipGetErrorString(e_));
+            ilqr_ws_destroy(ws); *out = nullptr;
+            return c_;
+        }
+    }
+#undef WSCHK
     return 0;
 }
 
@@ -1044,6 +1117,12 @@ int ilqr_rollout_batched(const ilqr_desc* d, const double* init_state, const dou
 {
     ilqr_ws* ws = nullptr;
     if (!init_state || !inputs_in || !params || !states || !inputs) return fail(-1, "null argument");
+    if (d && d->n_devices > 1)
+        return run_sharded(d, [&](const ilqr_desc& sd, long long lo) {
+            const long long n = SYSTEMS[sd.system_id].n, m = SYSTEMS[sd.system_id].m, np = SYSTEMS[sd.system_id].np, N = sd.n_timesteps;
+            return ilqr_rollout_batched(&sd, init_state + lo * n, inputs_in + lo * N * m, sd.params_batched ? params + lo * np : params,
+                                        states + lo * (N + 1) * n, inputs + lo * N * m);
+        });
     TRY(ilqr_ws_create(d, 0, &ws));
     TRY(ilqr_ws_upload(ws, ILQR_F_INIT, init_state, 0));
     TRY(ilqr_ws_upload(ws, ILQR_F_PARAMS, params, 0));
@@ -1059,6 +1138,12 @@ int ilqr_cost_batched(const ilqr_desc* d, const double* states, const double* in
 {
     ilqr_ws* ws = nullptr;
     if (!states || !inputs || !Rk || !QT || !target || !cost) return fail(-1, "null argument");
+    if (d && d->n_devices > 1)
+        return run_sharded(d, [&](const ilqr_desc& sd, long long lo) {
+            const long long n = SYSTEMS[sd.system_id].n, m = SYSTEMS[sd.system_id].m, N = sd.n_timesteps;
+            return ilqr_cost_batched(&sd, states + lo * (N + 1) * n, inputs + lo * N * m, Rk, QT, sd.target_batched ? target + lo * n : target,
+                                     cost + lo);
+        });
     TRY(ilqr_ws_create(d, 0, &ws));
     TRY(ilqr_ws_set_weights(ws, nullptr, Rk, QT));
     TRY(ilqr_ws_upload(ws, ILQR_F_TARGET, target, 0));
@@ -1075,6 +1160,13 @@ int ilqr_backward_batched(const ilqr_desc* d, const double* states, const double
 {
     ilqr_ws* ws = nullptr;
     if (!states || !inputs || !target || !Qk || !Rk || !QT || !params || !k || !K || !dJ) return fail(-1, "null argument");
+    if (d && d->n_devices > 1)
+        return run_sharded(d, [&](const ilqr_desc& sd, long long lo) {
+            const long long n = SYSTEMS[sd.system_id].n, m = SYSTEMS[sd.system_id].m, np = SYSTEMS[sd.system_id].np, N = sd.n_timesteps;
+            return ilqr_backward_batched(&sd, states + lo * (N + 1) * n, inputs + lo * N * m, sd.target_batched ? target + lo * n : target, Qk,
+                                         Rk, QT, sd.params_batched ? params + lo * np : params, k + lo * N * m, K + lo * N * m * n,
+                                         dJ + lo * 3, shard_ptr(status, lo));
+        });
     TRY(ilqr_ws_create(d, 0, &ws));
     TRY(ilqr_ws_set_weights(ws, Qk, Rk, QT));
     TRY(ilqr_ws_upload(ws, ILQR_F_TARGET, target, 0));
@@ -1101,6 +1193,14 @@ int ilqr_forward_batched(const ilqr_desc* d, const double* init_state, const dou
         return fail(-1, "null argument");
     const bool with_cost = cost != nullptr;
     if (with_cost && (!Rk || !QT || !target)) return fail(-1, "cost requested without Rk/QT/target");
+    if (d && d->n_devices > 1)
+        return run_sharded(d, [&](const ilqr_desc& sd, long long lo) {
+            const long long n = SYSTEMS[sd.system_id].n, m = SYSTEMS[sd.system_id].m, np = SYSTEMS[sd.system_id].np, N = sd.n_timesteps;
+            return ilqr_forward_batched(&sd, init_state + lo * n, ref_states + lo * (N + 1) * n, ref_inputs + lo * N * m, k + lo * N * m,
+                                        K + lo * N * m * n, learning_rate + lo, sd.params_batched ? params + lo * np : params,
+                                        states + lo * (N + 1) * n, inputs + lo * N * m, Rk, QT,
+                                        target && sd.target_batched ? target + lo * n : target, shard_ptr(cost, lo));
+        });
     TRY(ilqr_ws_create(d, 0, &ws));
     if (with_cost) {
         TRY(ilqr_ws_set_weights(ws, nullptr, Rk, QT));
@@ -1126,6 +1226,15 @@ int ilqr_solve_batched(const ilqr_desc* d, const double* init_state, const doubl
 {
     ilqr_ws* ws = nullptr;
     if (!init_state || !target || !guess || !Qk || !Rk || !QT || !params) return fail(-1, "null argument");
+    if (d && d->n_devices > 1)
+        return run_sharded(d, [&](const ilqr_desc& sd, long long lo) {
+            const long long n = SYSTEMS[sd.system_id].n, m = SYSTEMS[sd.system_id].m, np = SYSTEMS[sd.system_id].np, N = sd.n_timesteps;
+            return ilqr_solve_batched(&sd, init_state + lo * n, sd.target_batched ? target + lo * n : target, guess + lo * N * m, Qk, Rk, QT,
+                                      sd.params_batched ? params + lo * np : params, shard_ptr(states, lo * (N + 1) * n),
+                                      shard_ptr(inputs, lo * N * m), shard_ptr(k, lo * N * m), shard_ptr(K, lo * N * m * n),
+                                      shard_ptr(cost, lo), shard_ptr(iters, lo), shard_ptr(status, lo),
+                                      shard_ptr(trace, lo * (long long)sd.n_iterations * 6));
+        });
     TRY(ilqr_ws_create(d, trace != nullptr, &ws));
     TRY(ilqr_ws_set_weights(ws, Qk, Rk, QT));
     TRY(ilqr_ws_upload(ws, ILQR_F_INIT, init_state, 0));
@@ -1145,12 +1254,18 @@ int ilqr_solve_batched(const ilqr_desc* d, const double* init_state, const doubl
 }
 
 int ltvlqr_batched(const ilqr_desc* d, int32_t n_state_rows, const double* states, const double* inputs, const double* Qk,
-                   const double* Rk, const double* QT, const double* params, double* K)
+                   const double* Rk, const double* QT, const double* params, double* K, int32_t* status)
 {
     ilqr_ws* ws = nullptr;
     if (!states || !inputs || !Qk || !Rk || !QT || !params || !K) return fail(-1, "null argument");
     if (!d) return fail(-1, "null descriptor");
     if (n_state_rows < d->n_timesteps) return fail(-1, "states needs at least N=%d rows (got %d)", d->n_timesteps, n_state_rows);
+    if (d->n_devices > 1)
+        return run_sharded(d, [&](const ilqr_desc& sd, long long lo) {
+            const long long n = SYSTEMS[sd.system_id].n, m = SYSTEMS[sd.system_id].m, np = SYSTEMS[sd.system_id].np, N = sd.n_timesteps;
+            return ltvlqr_batched(&sd, n_state_rows, states + lo * n_state_rows * n, inputs + lo * N * m, Qk, Rk, QT,
+                                  sd.params_batched ? params + lo * np : params, K + lo * N * m * n, shard_ptr(status, lo));
+        });
     TRY(ilqr_ws_create(d, 0, &ws));
     TRY(ilqr_ws_set_weights(ws, Qk, Rk, QT));
     TRY(ilqr_ws_upload(ws, ILQR_F_PARAMS, params, 0));
@@ -1158,7 +1273,18 @@ int ltvlqr_batched(const ilqr_desc* d, int32_t n_state_rows, const double* state
     TRY(ilqr_ws_upload(ws, ILQR_F_INPUTS, inputs, 0));
     TRY(ilqr_ws_ltvlqr(ws));
     TRY(ilqr_ws_download(ws, ILQR_F_KFB, K));
-    return ilqr_ws_destroy(ws);
+    // R + B'PB exactly singular at some step (np.linalg.inv raises LinAlgError at ltvlqr.py:24): reported per problem when
+    // the caller passes `status`, else as an error of the call (the gains are written either way: inf / NaN from that step)
+    std::vector<int32_t> st((size_t)d->batch);
+    TRY(ilqr_ws_download(ws, ILQR_F_STATUS, st.data()));
+    long long bad = -1;
+    for (long long b = 0; b < d->batch; ++b) {
+        if (status) status[b] = st[b] == ILQR_STATUS_NUMERICAL ? ILQR_STATUS_NUMERICAL : 0;
+        if (st[b] == ILQR_STATUS_NUMERICAL && bad < 0) bad = b;
+    }
+    ilqr_ws_destroy(ws);
+    if (bad >= 0 && !status) return fail(ILQR_ERR_SINGULAR, "ltvlqr: R + B'PB is exactly singular (problem %lld): Singular matrix", bad);
+    return 0;
 }
 
 }  // extern "C"

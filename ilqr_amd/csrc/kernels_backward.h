@@ -354,8 +354,8 @@ __global__ void __launch_bounds__(64) k_riccati_quad(const KArgs a)
     const int bl = ((blockIdx.x & 3) << 4) + (lane >> 2);                              // problem within the tile
     const long long b = tile * TILE + bl;
     // overlapped with the accept step of the previous iteration (a.piped): that step's seg-0 block has not yet retired the
-    // problems whose search ran out (acc_j < 0), so they are masked here the way their cleared `active` would
-    const bool act = a.active[b] != 0 && (!a.piped || a.acc_j[b] >= 0);
+    // problems whose search ended the solve (ilqr.py:204), so they are masked here the way their cleared `active` would
+    const bool act = a.active[b] != 0 && (!a.piped || !ls_ends_solve(a, a.acc_j[b]));
     if (__ballot(act) == 0ull) return;
     const bool first_chunk = a.t_hi >= a.N, last_chunk = a.t_lo <= 0;
 #if RICCATI_QUAD_PRIO
@@ -403,7 +403,8 @@ __global__ void __launch_bounds__(64) k_riccati_quad(const KArgs a)
         ecr = vst[(size_t)(n * n + n) * TILE]; ecr_g = vst[(size_t)(n * n + n + 1) * TILE]; ecr_h = vst[(size_t)(n * n + n + 2) * TILE];
         ok = vst[(size_t)(n * n + n + 3) * TILE] != 0.0;
     }
-    constexpr int D = DEEP ? RICCATI_QUAD_PREFETCH_DEEP : RICCATI_QUAD_PREFETCH;
+    // (m > 1: the deep ring does not fit the register file next to a 2 x 2 inverse -- 700 B of spills per lane)
+    constexpr int D = DEEP && m == 1 ? RICCATI_QUAD_PREFETCH_DEEP : RICCATI_QUAD_PREFETCH;
     auto fetch = [&](const int tl, double (&A)[n * n], double (&Bm)[n * m], double (&u)[m], double (&Acr)[n]) {
         const double* l = Lp + (size_t)tl * NL * TILE;
         load_lin<S>(l, A, Bm, a.dt);

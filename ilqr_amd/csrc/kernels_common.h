@@ -60,6 +60,8 @@ struct KArgs {
     long long n_tiles;     // tiles this launch covers (a sub-batch of the workspace)
     long long tile0;       // first tile of the sub-batch
     double dt, low_red, armijo_thr, quu_reg;
+    double low_lr;         // ilqr.py:204: a search that ends with learning_rate < low_lr ends the solve
+    double alpha_end;      // learning_rate an exhausted search ends with: the first alpha_j <= search_floor (:185)
     double* X;             // [tile][state_rows][n][64]
     double* U;             // [tile][N][m][64]
     const double* G;       // [tile][N][m][64] initial guess (read by k_rollout only)
@@ -101,6 +103,13 @@ struct KArgs {
     long long Bpad;
 };
 
+// ilqr.py:204 after the line search of one problem: accj >= 0 accepted trial (learning_rate stays alpha_accj), accj < 0
+// exhausted (learning_rate has dropped to alpha_end).  True: "low learning rate", the solve of this problem ends.
+__device__ __forceinline__ bool ls_ends_solve(const KArgs& a, const int accj)
+{
+    return (accj >= 0 ? a.alphas[accj] : a.alpha_end) < a.low_lr;
+}
+
 // ------------------------------------------------------------------------------------------------
 // small dense helpers.  Every loop is fully unrolled so all arrays live in VGPRs; `kind` is the
 // compile-time sparsity class of the Jacobian entry ('0' zero, '1' one, 'x' general): after unrolling
@@ -119,14 +128,90 @@ template <class S>
 struct Riccati {
     static constexpr int n = S::n, m = S::m;
 
+    // np.linalg.inv (ilqr.py:106, ltvlqr.py:24) for a matrix the Cholesky path below cannot take: LU with partial (row)
+    // pivoting, then one solve per identity column -- LAPACK getrf/getri's rule, the arithmetic of oracle/ilqr_oracle.c
+    // inv_small.  Returns false only on an exactly zero pivot, the one case in which numpy raises LinAlgError; a NaN or
+    // indefinite Q is inverted like any other (NaN in, NaN out: the line search then rejects every trial and the
+    // problem ends "low learning rate" as it does in the reference).  Row swaps are selects: everything stays in VGPRs.
+    static __device__ __forceinline__ bool inv_lu(const double (&Q)[m * m], double (&Qi)[m * m])
+    {
+        double a[m * m];
+        int piv[m];
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < m * m; ++i) a[i] = Q[i];
+#pragma unroll
+        for (int c = 0; c < m; ++c) {
+            int pr = c;
+            double best = __builtin_fabs(a[c * m + c]);
+#pragma unroll
+            for (int r = c + 1; r < m; ++r) {
+                const double v = __builtin_fabs(a[r * m + c]);
+                if (v > best) { best = v; pr = r; }
+            }
+            piv[c] = pr;
+            ok = ok && !(best == 0.0);
+#pragma unroll
+            for (int r = c + 1; r < m; ++r)
+#pragma unroll
+                for (int j = 0; j < m; ++j) {
+                    const double x = a[c * m + j], y = a[r * m + j];
+                    a[c * m + j] = pr == r ? y : x;
+                    a[r * m + j] = pr == r ? x : y;
+                }
+#pragma unroll
+            for (int r = c + 1; r < m; ++r) {
+                a[r * m + c] = a[r * m + c] / a[c * m + c];
+#pragma unroll
+                for (int j = c + 1; j < m; ++j) a[r * m + j] = a[r * m + j] - a[r * m + c] * a[c * m + j];
+            }
+        }
+#pragma unroll
+        for (int col = 0; col < m; ++col) {
+            double b[m];
+#pragma unroll
+            for (int i = 0; i < m; ++i) b[i] = i == col ? 1.0 : 0.0;
+#pragma unroll
+            for (int c = 0; c < m; ++c)
+#pragma unroll
+                for (int r = c + 1; r < m; ++r) {
+                    const double x = b[c], y = b[r];
+                    b[c] = piv[c] == r ? y : x;
+                    b[r] = piv[c] == r ? x : y;
+                }
+#pragma unroll
+            for (int i = 0; i < m; ++i)
+#pragma unroll
+                for (int j = 0; j < i; ++j) b[i] = b[i] - a[i * m + j] * b[j];
+#pragma unroll
+            for (int i = m - 1; i >= 0; --i) {
+#pragma unroll
+                for (int j = i + 1; j < m; ++j) b[i] = b[i] - a[i * m + j] * b[j];
+                b[i] = b[i] / a[i * m + i];
+            }
+#pragma unroll
+            for (int i = 0; i < m; ++i) Qi[i * m + col] = b[i];
+        }
+        return ok;
+    }
+
     // inverse of the m x m matrix Q (row-major).  m == 1: reciprocal (what LAPACK getri does for 1x1).
-    // m > 1: Cholesky L L^T, inv = L^-T L^-1.  Returns false when Q is not positive definite / not finite.
+    // m > 1: Cholesky L L^T, inv = L^-T L^-1 while Q is positive definite (every Q_uu of a well-posed problem); a Q that
+    // is not (indefinite weights, a diverged trajectory's NaN) takes inv_lu, numpy's own rule.  Returns false only where
+    // np.linalg.inv raises: an exactly zero pivot.
     static __device__ __forceinline__ bool inv_spd(const double (&Q)[m * m], double (&Qi)[m * m])
     {
         if constexpr (m == 1) {
             Qi[0] = 1.0 / Q[0];
             return Q[0] != 0.0;
         } else {
+            if (inv_chol(Q, Qi)) return true;
+            return inv_lu(Q, Qi);
+        }
+    }
+    static __device__ __forceinline__ bool inv_chol(const double (&Q)[m * m], double (&Qi)[m * m])
+    {
+        {
             // 1 / L_jj is computed once per pivot (IEEE division) and reused for the diagonal of L^-1.  The off-diagonal
             // divisions stay divisions: replacing them by reciprocal multiplies moved the quadcopter's final K from
             // < 1e-8 to 2.5e-8 of the reference after 21 iterations (the inverse is where rounding is amplified most).

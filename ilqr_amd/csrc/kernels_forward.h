@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(64) k_forward(const KArgs a)
         accj = act ? a.acc_j[b] : -1;
         run = act && accj >= 0;
         alpha = a.alphas[accj >= 0 ? accj : 0];
-        if (act && accj < 0) { a.status[b] = ILQR_STATUS_LOW_LR; a.active[b] = 0; }    // :204-207
+        if (act && ls_ends_solve(a, accj)) { a.status[b] = ILQR_STATUS_LOW_LR; a.active[b] = 0; }   // :204-207
         if (__ballot(run) == 0ull) return;
     } else {
         alpha = a.alpha_pp[b];
@@ -552,8 +552,8 @@ __global__ void __launch_bounds__(64) k_accept_lin(const KArgs a)
         (void)closed_loop_range<S, true, false, ACCEPT_FUSES_LINEARIZE != 0>(a, Xp, Up, Kp, kp, XOp, UOp, nullptr, x, p, Rk, alpha, t0, t1, Xfirst, Lp);
     }
     if (seg == 0 && act) {                                                             // per-problem bookkeeping, once
-        if (accj < 0) { a.status[b] = ILQR_STATUS_LOW_LR; a.active[b] = 0; }           // :204-207
-        else {
+        if (ls_ends_solve(a, accj)) { a.status[b] = ILQR_STATUS_LOW_LR; a.active[b] = 0; }   // :204-207
+        if (accj >= 0) {
             const double nc = a.new_cost[b];
             a.cost[b] = nc;                                                            // :197
             a.accepts[b] += 1;

@@ -16,7 +16,8 @@ from .symbolic_dynamics import system_of
 
 class ilqr:
     def __init__(self, init_state, target_state, initial_guess, dt, start_time, end_time, f_disc, A, B, Q_k, R_k, Q_T,
-                 parameters, n_iterations, device=0, n_alpha_parallel=0, verbose=None, zero_first_state=True, pipeline=0, n_streams=0):
+                 parameters, n_iterations, device=0, n_alpha_parallel=0, verbose=None, zero_first_state=True, pipeline=0, n_streams=0,
+                 n_devices=1):
         self.init_state_ = init_state
         self.target_state_ = target_state
         self.inputs_ = initial_guess
@@ -49,6 +50,9 @@ class ilqr:
         self.zero_first_state_ = zero_first_state
         self.pipeline_ = pipeline              # 0 auto, 1 fused, 2 split kernel schedule (same results)
         self.n_streams_ = n_streams            # independent sub-batches of solve(), one HIP stream each
+        # GPUs the batch is split over by problem index (device, device + 1, ...; 0 = every visible GPU): one host
+        # thread per GPU inside the library, no exchange between them -- the problems are independent
+        self.n_devices_ = n_devices
         self.verbose_ = (not self.batched_) if verbose is None else verbose
 
         n, m, npar = _lib.system_dims(self.system_)
@@ -58,14 +62,35 @@ class ilqr:
         if np.shape(initial_guess)[-2] != self.n_timesteps_:
             raise ValueError('initial_guess has %d rows but np.arange(start_time, end_time, dt) has %d steps'
                              % (np.shape(initial_guess)[-2], self.n_timesteps_))
-        if np.size(_lib.params_of(self.system_, parameters)) % npar != 0 or np.size(_lib.params_of(self.system_, parameters)) == 0:
-            raise ValueError('%s takes %d parameters' % (self.system_, npar))
+        # Every array is handed to C as a raw pointer: shapes are settled here.  With a batch, init_state is (B,n) -- or
+        # (n,), one initial state shared by the B guesses --, target_state (n,) or (B,n), parameters (P,) or (B,P).
+        Bn = self.batch_
+        init_shape, tgt_shape = np.shape(init_state), np.shape(target_state)
+        par_shape = np.shape(_lib.params_of(self.system_, parameters))
+        if np.ndim(initial_guess) not in (2, 3):
+            raise ValueError('initial_guess must be (N,m) or (B,N,m), got %s' % (np.shape(initial_guess),))
+        if init_shape not in (((n,), (Bn, n)) if self.batched_ else ((n,),)):
+            raise ValueError('init_state must be (%d,)%s, got %s' % (n, ' or (%d,%d)' % (Bn, n) if self.batched_ else '', init_shape))
+        if tgt_shape not in (((n,), (Bn, n)) if self.batched_ else ((n,),)):
+            raise ValueError('target_state must be (%d,)%s, got %s' % (n, ' or (%d,%d)' % (Bn, n) if self.batched_ else '', tgt_shape))
+        if par_shape not in (((npar,), (Bn, npar)) if self.batched_ else ((npar,),)):
+            raise ValueError('%s takes parameters of shape (%d,)%s, got %s'
+                             % (self.system_, npar, ' or (%d,%d)' % (Bn, npar) if self.batched_ else '', par_shape))
+        for name, w, k_ in (('Q_k', Q_k, n), ('R_k', R_k, m), ('Q_T', Q_T, n)):
+            if np.size(w) != k_ * k_:
+                raise ValueError('%s must be (%d,%d), got %s' % (name, k_, k_, np.shape(w)))
 
     # ------------------------------------------------------------------ helpers
-    def _b(self, a, tail_ndim):
-        """float64 contiguous with a leading batch axis."""
+    def _b(self, a, tail_shape, name='array'):
+        """float64 contiguous, shape (B,) + tail_shape: the C side reads exactly that many doubles."""
         a = _lib.f64(a)
-        return a if a.ndim == tail_ndim + 1 else a[None]
+        if a.shape == tuple(tail_shape) and (not self.batched_ or len(tail_shape) == 1):
+            # a single problem, or one vector shared by the whole batch (init_state (n,) with B guesses)
+            a = np.ascontiguousarray(np.broadcast_to(a, (self.batch_,) + tuple(tail_shape)))
+        if a.shape != (self.batch_,) + tuple(tail_shape):
+            raise ValueError('%s must have shape %s%s, got %s' % (name, (self.batch_,) + tuple(tail_shape) if self.batched_ else tuple(tail_shape),
+                                                                   '' if self.batched_ else ' (single problem)', a.shape))
+        return a
 
     def _unb(self, a):
         return a if self.batched_ else a[0]
@@ -86,15 +111,17 @@ class ilqr:
         _lib.require_gpu()
         _, tb = self._target()
         _, pb = self._params()
+        n_dev = self.n_devices_ if self.n_devices_ else _lib.lib().ilqr_device_count()
         return _lib.make_desc(self.system_, self.n_timesteps_, self.batch_, self.dt_, n_iterations=n_iterations,
                               n_alpha_parallel=self.n_alpha_parallel_, zero_first_state=self.zero_first_state_,
-                              device=self.device_, target_batched=tb, params_batched=pb, pipeline=self.pipeline_, n_streams=self.n_streams_)
+                              device=self.device_, target_batched=tb, params_batched=pb, pipeline=self.pipeline_, n_streams=self.n_streams_,
+                              n_devices=n_dev)
 
     # ------------------------------------------------------------------ ilqr.py:30-47
     def rollout(self):
         Bn, N, n, m = self.batch_, self.n_timesteps_, self.n_states_, self.n_inputs_
-        init = self._b(self.init_state_, 1)
-        u_in = self._b(self.inputs_, 2)
+        init = self._b(self.init_state_, (n,), 'init_state')
+        u_in = self._b(self.inputs_, (N, m), 'inputs_')
         params, _ = self._params()
         states = np.empty((Bn, N + 1, n))
         inputs = np.empty((Bn, N, m))
@@ -106,8 +133,9 @@ class ilqr:
 
     # ------------------------------------------------------------------ ilqr.py:49-62
     def compute_cost(self, states, inputs):
-        states = self._b(states, 2)
-        inputs = self._b(inputs, 2)
+        N, n, m = self.n_timesteps_, self.n_states_, self.n_inputs_
+        states = self._b(states, (N + 1, n), 'states')
+        inputs = self._b(inputs, (N, m), 'inputs')
         _, Rk, QT = self._weights()
         target, _ = self._target()
         cost = np.empty(self.batch_)
@@ -118,8 +146,8 @@ class ilqr:
     # ------------------------------------------------------------------ ilqr.py:64-135
     def backwards_pass(self):
         Bn, N, n, m = self.batch_, self.n_timesteps_, self.n_states_, self.n_inputs_
-        states = self._b(self.states_, 2)
-        inputs = self._b(self.inputs_, 2)
+        states = self._b(self.states_, (N + 1, n), 'states_')
+        inputs = self._b(self.inputs_, (N, m), 'inputs_')
         Qk, Rk, QT = self._weights()
         target, _ = self._target()
         params, _ = self._params()
@@ -142,11 +170,11 @@ class ilqr:
     # ------------------------------------------------------------------ ilqr.py:137-158
     def forwards_pass(self, learning_rate):
         Bn, N, n, m = self.batch_, self.n_timesteps_, self.n_states_, self.n_inputs_
-        init = self._b(self.init_state_, 1)
-        ref_states = self._b(self.states_, 2)
-        ref_inputs = self._b(self.inputs_, 2)
-        k = self._b(self.k_feedforward_, 2)
-        K = self._b(self.K_feedback_, 3)
+        init = self._b(self.init_state_, (n,), 'init_state')
+        ref_states = self._b(self.states_, (N + 1, n), 'states_')
+        ref_inputs = self._b(self.inputs_, (N, m), 'inputs_')
+        k = self._b(self.k_feedforward_, (N, m), 'k_feedforward_')
+        K = self._b(self.K_feedback_, (N, m, n), 'K_feedback_')
         params, _ = self._params()
         lr = np.ascontiguousarray(np.broadcast_to(np.asarray(learning_rate, dtype=np.float64), (Bn,)))
         states = np.empty((Bn, N + 1, n))
@@ -163,8 +191,8 @@ class ilqr:
             # the reference falls off the loop with k_feedforward unbound (ilqr.py:211)
             raise UnboundLocalError("local variable 'k_feedforward' referenced before assignment")
         Bn, N, n, m = self.batch_, self.n_timesteps_, self.n_states_, self.n_inputs_
-        init = self._b(self.init_state_, 1)
-        guess = self._b(self.inputs_, 2)
+        init = self._b(self.init_state_, (n,), 'init_state')
+        guess = self._b(self.inputs_, (N, m), 'inputs_')
         Qk, Rk, QT = self._weights()
         target, _ = self._target()
         params, _ = self._params()

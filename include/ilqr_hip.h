@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ILQR_ABI_VERSION 5
+#define ILQR_ABI_VERSION 6
 
 /* systems compiled into the library (sympy-generated __device__ dynamics, ilqr_amd/csrc/dynamics/) */
 enum { ILQR_SYS_PENDULUM = 0, ILQR_SYS_ACROBOT = 1, ILQR_SYS_CARTPOLE = 2, ILQR_SYS_QUADCOPTER = 3, ILQR_SYS_CAR = 4,
@@ -36,7 +36,7 @@ enum {
     ILQR_STATUS_MAX_ITER = 0,   /* loop ran n_iterations times (ilqr.py:170) */
     ILQR_STATUS_OPTIMAL = 1,    /* |expected reduction| < low_expected_reduction (ilqr.py:175-179) */
     ILQR_STATUS_LOW_LR = 2,     /* line search exhausted (ilqr.py:204-207) */
-    ILQR_STATUS_NUMERICAL = 3   /* Q_uu exactly singular / not positive definite (numpy would raise, ilqr.py:106) */
+    ILQR_STATUS_NUMERICAL = 3   /* Q_uu exactly singular: a zero pivot, where np.linalg.inv raises LinAlgError (ilqr.py:106) */
 };
 
 /* problem descriptor.  Fill with ilqr_desc_default() first. */
@@ -50,7 +50,7 @@ typedef struct ilqr_desc {
     int32_t zero_first_state;     /* 1 (default): row 0 of states is zero as in the reference (ilqr.py:31-42,143,153) */
     int32_t device;               /* HIP device ordinal */
     double learning_speed;        /* 0.95  ilqr.py:166 */
-    double low_learning_rate;     /* 0.05  ilqr.py:167 and the literal at :185 */
+    double low_learning_rate;     /* 0.05  ilqr.py:167: after the search, learning_rate < this ends the solve (:204) */
     double low_expected_reduction;/* 1e-3  ilqr.py:168 */
     double armijo_threshold;      /* 0.1   ilqr.py:169 */
     double quu_reg;               /* added to diag(Q_uu); 0 = reference behaviour (ilqr.py:106 has none) */
@@ -72,6 +72,20 @@ typedef struct ilqr_desc {
                                      iteration i + 1 (which walks the horizon from its end) run overlapped on two HIP
                                      streams, in chunks.  0 auto (on when the horizon gives at least 4 chunks of 4 segments of
                                      64 steps), 1 off, 2 on from two segments up.  Results do not depend on it. */
+    double search_floor;          /* 0.05  the LITERAL in `while learning_rate > 0.05 and armijo_flag == 0` (ilqr.py:185):
+                                     trials alpha_j = learning_speed^j run while alpha_j > search_floor.  The reference keeps
+                                     it apart from low_learning_rate (:167, used at :204 only); so does this library: a trial
+                                     accepted at alpha < low_learning_rate is taken AND ends the solve ("low learning rate"),
+                                     and an exhausted search ends it only if the next alpha is < low_learning_rate. */
+    int32_t n_devices;            /* one-shot host entry points (ilqr_*_batched, ltvlqr_batched): 0/1 = the whole batch on
+                                     `device`; G > 1 = the batch is split into G contiguous shards by problem index (sizes
+                                     differ by at most one, remainder to the first shards), shard r on device `device + r`,
+                                     one host thread per shard, every shard reading and writing its own slice of the
+                                     caller's arrays.  Problems are independent (no term of ilqr.py / ltvlqr.py couples
+                                     two): no collective, results identical to the single-device call.  The workspace API
+                                     is per device (ilqr_ws_create ignores this field). */
+    int32_t device_wrap;          /* 0: a shard whose device ordinal is not visible is an error; 1: ordinals wrap modulo the
+                                     visible devices (several shards per GPU: tests on a one-GPU box) */
 } ilqr_desc;
 
 void ilqr_desc_default(ilqr_desc* d);
@@ -121,9 +135,12 @@ int ilqr_solve_batched(const ilqr_desc* d, const double* init_state, const doubl
                        double* inputs, double* k, double* K, double* cost, int32_t* iters, int32_t* status, double* trace);
 
 /* ltvlqr(): python/ltvlqr.py:3-28.  states (B,n_state_rows>=N,n) (rows 0..N-1 read), inputs (B,N,m) -> K (B,N,m,n).
- * d->n_iterations and the line-search fields are ignored. */
+ * d->n_iterations and the line-search fields are ignored.  np.linalg.inv raises LinAlgError when R + B'PB is exactly
+ * singular (ltvlqr.py:24): status (optional, (B)) receives 0 or ILQR_STATUS_NUMERICAL per problem; without it the call
+ * returns ILQR_ERR_SINGULAR if any problem hit that case (K is written either way). */
+#define ILQR_ERR_SINGULAR (-5)
 int ltvlqr_batched(const ilqr_desc* d, int32_t n_state_rows, const double* states, const double* inputs, const double* Qk,
-                   const double* Rk, const double* QT, const double* params, double* K);
+                   const double* Rk, const double* QT, const double* params, double* K, int32_t* status);
 
 /* ---- device-resident workspace: the same passes with the batch kept in HBM between calls ----
  * (no counterpart in the reference, whose arrays are numpy objects; this is the form bench.py and

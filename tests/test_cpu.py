@@ -175,7 +175,7 @@ def test_library_exports_every_declared_symbol():
     for nme in names:
         assert hasattr(handle, nme), nme
     assert sorted(_lib.SIGNATURES) == names      # the python binding covers the header exactly
-    assert _lib.lib().ilqr_abi_version() == 5
+    assert _lib.lib().ilqr_abi_version() == 6
 
 
 def test_library_host_side_calls_without_gpu():
@@ -209,6 +209,27 @@ def test_dropin_rejects_foreign_callables_and_bad_shapes():
     sb = ilqr_amd.ilqr(np.zeros((3, 2)), np.zeros(2), np.zeros((3, 10, 1)), 0.1, 0, 1, f, A, B, np.eye(2), np.eye(1),
                        np.eye(2), np.ones(3), 5)
     assert sb.batched_ and sb.batch_ == 3
+    # every array reaches C as a raw pointer: a shape the C side would read out of bounds is a ValueError here
+    w = (0.1, 0, 1, f, A, B, np.eye(2), np.eye(1), np.eye(2))
+    shared = ilqr_amd.ilqr(np.zeros(2), np.zeros(2), np.zeros((3, 10, 1)), *w, np.ones(3), 5)     # one init_state, 3 guesses
+    assert shared._b(shared.init_state_, (2,), 'init_state').shape == (3, 2)
+    for bad in (dict(init=np.zeros((2, 2))), dict(target=np.zeros((2, 2))), dict(target=np.zeros((1, 2))), dict(params=np.ones((1, 3))),
+                dict(params=np.ones((2, 3))), dict(params=np.ones(6)), dict(init=np.zeros((3, 3)))):
+        a = dict(init=np.zeros((3, 2)), target=np.zeros(2), params=np.ones(3))
+        a.update(bad)
+        with pytest.raises(ValueError):
+            ilqr_amd.ilqr(a['init'], a['target'], np.zeros((3, 10, 1)), *w, a['params'], 5)
+    with pytest.raises(ValueError):
+        ilqr_amd.ilqr(np.zeros((1, 2)), np.zeros(2), np.zeros((10, 1)), *w, np.ones(3), 5)       # batched init, single guess
+    with pytest.raises(ValueError):
+        ilqr_amd.ilqr(np.zeros(2), np.zeros(2), np.zeros((10, 1)), 0.1, 0, 1, f, A, B, np.eye(3), np.eye(1), np.eye(2), np.ones(3), 5)
+    with pytest.raises(ValueError):
+        sb._b(np.zeros((2, 11, 2)), (11, 2), 'states')                                           # compute_cost / forwards_pass inputs
+    with pytest.raises(ValueError):
+        sb._b(np.zeros((3, 10, 2)), (11, 2), 'states')
+    with pytest.raises(ValueError):
+        s._b(np.zeros((3, 11, 2)), (11, 2), 'states')                                            # a batch handed to a single problem
+    assert sb._b(np.zeros((3, 11, 2)), (11, 2), 'states').shape == (3, 11, 2) and s._b(np.zeros((11, 2)), (11, 2)).shape == (1, 11, 2)
 
 
 # ------------------------------------------------------------------------------------------ sharding (N > 1 path)
