@@ -24,6 +24,8 @@ KERNEL_NAMES = ('rollout', 'backward', 'linesearch', 'accept', 'ltvlqr', 'forwar
 
 
 ERR_SINGULAR = -5      # ILQR_ERR_SINGULAR: np.linalg.inv would have raised LinAlgError
+ERR_SCRATCH = -6       # ILQR_ERR_SCRATCH: ltvlqr_device_noalloc, batch larger than the static scratch array
+NOALLOC_SCRATCH_BYTES = 64 * 1024 * 1024
 
 
 class IlqrHipError(RuntimeError):
@@ -60,6 +62,7 @@ SIGNATURES = {
     'ilqr_forward_batched': (C.c_int, [_DESCP] + [_dp] * 13),
     'ilqr_solve_batched': (C.c_int, [_DESCP] + [_dp] * 12 + [_ip, _ip, _dp]),
     'ltvlqr_batched': (C.c_int, [_DESCP, C.c_int32] + [_dp] * 7 + [_ip]),
+    'ltvlqr_device_noalloc': (C.c_int, [_DESCP, C.c_int32] + [C.c_void_p] * 7 + [C.c_void_p, C.c_void_p]),
     'ilqr_ws_create': (C.c_int, [_DESCP, C.c_int32, C.POINTER(_WS)]),
     'ilqr_ws_destroy': (C.c_int, [_WS]),
     'ilqr_ws_set_weights': (C.c_int, [_WS, _dp, _dp, _dp]),

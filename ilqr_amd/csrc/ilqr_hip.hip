@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -1288,3 +1289,87 @@ int ltvlqr_batched(const ilqr_desc* d, int32_t n_state_rows, const double* state
 }
 
 }  // extern "C"
+
+// -------------------------------------------------------------------------- ltvlqr without allocating
+// ltvlqr_device_noalloc: ltvlqr_batched for callers that cannot allocate (include/ilqr_hip.h).  Everything
+// ltvlqr_batched keeps in a workspace it hipMallocs -- the tiled copies of the trajectory and of the gains, the
+// parameters and weights, the status flags, LIN for n > 4 -- lives in ONE static device array instead.  The array's name
+// is a host-side stand-in, not a device address: the address on each GPU comes from hipGetSymbolAddress, once per device
+// with that device current, and only that pointer is handed to kernels, memsets and copies.
+static __device__ __align__(256) unsigned char scratch[ILQR_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int NOALLOC_MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[NOALLOC_MAX_DEVICES];     // per device: each GPU holds its own copy of the array
+
+// the address of `scratch` on `device` (which must be the current device), resolved on the first call per device
+int scratch_on_device(int device, unsigned char** out)
+{
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return fail(-1, "device %d out of range", device);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(-100, "hipGetSymbolAddress(scratch) returned a null address on device %d", device);
+        g_scratch_ptr[device] = (unsigned char*)p;
+    }
+    *out = g_scratch_ptr[device];
+    return 0;
+}
+}  // namespace
+
+extern "C" int ltvlqr_device_noalloc(const ilqr_desc* d, int32_t n_state_rows, const double* states, const double* inputs,
+                                     const double* Qk, const double* Rk, const double* QT, const double* params, double* K,
+                                     int32_t* status, void* stream)
+{
+    if (!states || !inputs || !Qk || !Rk || !QT || !params || !K) return fail(-1, "null argument");
+    int rc = validate_desc(d);
+    if (rc) return rc;
+    if (d->n_devices > 1) return fail(-1, "ltvlqr_device_noalloc runs on one device (n_devices = %d)", d->n_devices);
+    if (n_state_rows < d->n_timesteps) return fail(-1, "states needs at least N=%d rows (got %d)", d->n_timesteps, n_state_rows);
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (d->device < 0 || d->device >= ndev) return fail(-1, "device %d out of range (%d visible)", d->device, ndev);
+    HIPCHK(hipSetDevice(d->device));
+    unsigned char* base = nullptr;
+    if ((rc = scratch_on_device(d->device, &base))) return rc;
+    // a workspace whose arrays are slices of the scratch array; nothing in it owns memory
+    ilqr_ws w{};
+    w.d = *d;
+    w.n = SYSTEMS[d->system_id].n; w.m = SYSTEMS[d->system_id].m; w.np = SYSTEMS[d->system_id].np;
+    w.N = d->n_timesteps; w.B = d->batch;
+    w.tiles = (w.B + TILE - 1) / TILE; w.Bpad = w.tiles * TILE;
+    w.state_rows = w.N + 1;
+    w.stream = (hipStream_t)stream;
+    w.n_sub = 1;
+    w.grp = w.n > 4;                                    // as ilqr_ws_create: P of n > 4 does not fit one lane
+    w.n_lin = with_system(d->system_id, [&](auto S) { return Lin<decltype(S)>::n_lin; });
+    const size_t Bp = (size_t)w.Bpad, n = w.n, m = w.m, np = w.np, N = w.N;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t oX = carve(Bp * (N + 1) * n * 8), oU = carve(Bp * N * m * 8), oK = carve(Bp * N * m * n * 8),
+                 oP = carve(Bp * np * 8), oW = carve((2 * n * n + m * m) * 8), oS = carve(Bp * 4),
+                 oL = carve(w.grp ? Bp * N * (size_t)w.n_lin * 8 : 0);
+    if (off > (size_t)ILQR_NOALLOC_SCRATCH_BYTES) {
+        const size_t per_tile = off / (size_t)w.tiles + 1;
+        return fail(ILQR_ERR_SCRATCH, "ltvlqr_device_noalloc: %lld problems x %d steps need %zu bytes of scratch, the static array holds %zu "
+                    "(about %zu problems at this horizon); use ltvlqr_batched or a workspace for larger batches",
+                    (long long)w.B, w.N, off, (size_t)ILQR_NOALLOC_SCRATCH_BYTES, (size_t)ILQR_NOALLOC_SCRATCH_BYTES / per_tile * TILE);
+    }
+    w.X = (double*)(base + oX); w.U = (double*)(base + oU); w.KFB = (double*)(base + oK); w.PARAMS = (double*)(base + oP);
+    w.WTS = (double*)(base + oW); w.status = (int*)(base + oS); w.LIN = w.grp ? (double*)(base + oL) : nullptr;
+    w.hbm_bytes = off;
+    // the array keeps the last call's contents: the status flags must start at zero (the kernels only ever set them)
+    HIPCHK(hipMemsetAsync(w.status, 0, Bp * 4, w.stream));
+    HIPCHK(hipMemcpyAsync(w.WTS, Qk, n * n * 8, hipMemcpyDeviceToDevice, w.stream));
+    HIPCHK(hipMemcpyAsync(w.WTS + n * n, Rk, m * m * 8, hipMemcpyDeviceToDevice, w.stream));
+    HIPCHK(hipMemcpyAsync(w.WTS + n * n + m * m, QT, n * n * 8, hipMemcpyDeviceToDevice, w.stream));
+    if ((rc = do_upload(&w, ILQR_F_PARAMS, params, true, 0))) return rc;
+    if ((rc = do_upload(&w, ILQR_F_STATES, states, true, n_state_rows))) return rc;
+    if ((rc = do_upload(&w, ILQR_F_INPUTS, inputs, true, 0))) return rc;
+    if ((rc = ilqr_ws_ltvlqr(&w))) return rc;
+    if ((rc = do_download(&w, ILQR_F_KFB, K, true))) return rc;
+    if (status && (rc = do_download(&w, ILQR_F_STATUS, status, true))) return rc;
+    return 0;
+}

@@ -142,6 +142,24 @@ int ilqr_solve_batched(const ilqr_desc* d, const double* init_state, const doubl
 int ltvlqr_batched(const ilqr_desc* d, int32_t n_state_rows, const double* states, const double* inputs, const double* Qk,
                    const double* Rk, const double* QT, const double* params, double* K, int32_t* status);
 
+/* ltvlqr_batched for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
+ * cannot call hipMalloc -- code under HIP graph capture, tight serving loops (an MPC controller refreshing its gain
+ * schedule every control step), harnesses that forbid allocation.  Same kernels and results as ltvlqr_batched.
+ *   - EVERY pointer is a DEVICE pointer: states (B,n_state_rows,n), inputs (B,N,m), Qk (n,n), Rk (m,m), QT (n,n),
+ *     params (P)|(B,P) in, K (B,N,m,n) and the optional status (B) (0 / ILQR_STATUS_NUMERICAL) out.
+ *   - The call enqueues its work on `stream` (a hipStream_t; NULL = the default stream) and returns without waiting.
+ *   - It calls no hipMalloc / hipFree: the tiled copies of the trajectory and gains live in a static device array of
+ *     ILQR_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.  A batch that does
+ *     not fit is refused with ILQR_ERR_SCRATCH (the message names the largest batch for that horizon: about
+ *     64 * floor(64 MiB / (64 * 8 * ((N+1) n + N m + N m n + P))) problems, e.g. 256 acrobot problems of 3000 steps).
+ *   - Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race.
+ *     d->n_devices must be 0 or 1. */
+#define ILQR_NOALLOC_SCRATCH_BYTES (64 * 1024 * 1024)
+#define ILQR_ERR_SCRATCH (-6)
+int ltvlqr_device_noalloc(const ilqr_desc* d, int32_t n_state_rows, const double* states, const double* inputs,
+                          const double* Qk, const double* Rk, const double* QT, const double* params, double* K,
+                          int32_t* status, void* stream);
+
 /* ---- device-resident workspace: the same passes with the batch kept in HBM between calls ----
  * (no counterpart in the reference, whose arrays are numpy objects; this is the form bench.py and
  * long-running callers use so that the timed region starts with inputs resident in HBM). */
