@@ -83,6 +83,7 @@ SIGNATURES = {
     'ilqr_ws_profile': (C.c_int, [_WS, C.c_int32]),
     'ilqr_ws_profile_read': (C.c_int, [_WS, _dp, C.POINTER(C.c_int64)]),
     'ilqr_ws_info': (C.c_int, [_WS, _ip, _ip, C.POINTER(C.c_int64)]),
+    'ilqr_ws_ls_schedule': (C.c_int, [_WS, _ip, _ip]),
     'ilqr_ws_pipeline': (C.c_int, [_WS]),
 }
 
@@ -272,5 +273,8 @@ class Workspace:
     def info(self):
         w, t, b = C.c_int32(), C.c_int32(), C.c_int64()
         check(lib().ilqr_ws_info(self._h, C.byref(w), C.byref(t), C.byref(b)))
-        return dict(n_alpha_parallel=w.value, n_trials=t.value, hbm_bytes=b.value,
+        nr = C.c_int32()
+        widths = (C.c_int32 * 64)()
+        check(lib().ilqr_ws_ls_schedule(self._h, C.byref(nr), widths))
+        return dict(n_alpha_parallel=w.value, n_trials=t.value, hbm_bytes=b.value, ls_widths=[int(widths[i]) for i in range(nr.value)],
                     pipeline={1: 'fused', 2: 'split'}[check(lib().ilqr_ws_pipeline(self._h))])

@@ -880,7 +880,14 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
         }
     }
     if (ws->overlap) {
-        WSCHK(hipStreamCreate(&ws->pipe_stream));
+        // A stream of its own priority class: HIP deals streams of one priority round-robin over a few hardware queues
+        // (4 per process here), so with other streams alive in the process (torch, RCCL) `stream` and a plain second
+        // stream can land on the SAME queue and the overlapped pair runs back to back (measured under
+        // torch.distributed: recursion 1.6 -> 2.6 ms, 61 -> 72 ms per solve).  High-priority streams have their own
+        // queues -- and the recursion is the critical path of the pair.
+        int prio_least = 0, prio_greatest = 0;
+        WSCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        WSCHK(hipStreamCreateWithPriority(&ws->pipe_stream, hipStreamDefault, prio_greatest));
         for (int c = 0; c < OVERLAP_CHUNKS; ++c) WSCHK(hipEventCreateWithFlags(&ws->pipe_ev[c], hipEventDisableTiming));
         WSCHK(hipEventCreateWithFlags(&ws->pipe_done, hipEventDisableTiming));
     }
@@ -1101,6 +1108,14 @@ int ilqr_ws_info(ilqr_ws* ws, int32_t* W, int32_t* n_trials, int64_t* hbm_bytes)
     if (W) *W = ws->W;
     if (n_trials) *n_trials = ws->n_trials;
     if (hbm_bytes) *hbm_bytes = (int64_t)ws->hbm_bytes;
+    return 0;
+}
+
+int ilqr_ws_ls_schedule(ilqr_ws* ws, int32_t* n_rounds, int32_t* widths)
+{
+    if (!ws) return fail(-1, "null workspace");
+    if (n_rounds) *n_rounds = ws->ls_rounds_n;
+    if (widths) for (int r = 0; r < ws->ls_rounds_n; ++r) widths[r] = ws->ls_width[r];
     return 0;
 }
 

@@ -211,6 +211,10 @@ int ilqr_ws_sync(ilqr_ws* ws);
 int ilqr_ws_profile(ilqr_ws* ws, int32_t enable);
 int ilqr_ws_profile_read(ilqr_ws* ws, double* ms /*8*/, int64_t* launches /*8*/);
 int ilqr_ws_info(ilqr_ws* ws, int32_t* n_alpha_parallel, int32_t* n_trials, int64_t* hbm_bytes);
+/* the line-search schedule of this workspace: n_rounds launches of k_linesearch per search, round r evaluating widths[r]
+ * consecutive trials per problem (widths: room for 64 entries).  Fixed width n_alpha_parallel, or 4,4,8,16,... when auto
+ * on a large batch; results do not depend on it. */
+int ilqr_ws_ls_schedule(ilqr_ws* ws, int32_t* n_rounds, int32_t* widths);
 int ilqr_ws_pipeline(ilqr_ws* ws);         /* 1 fused, 2 split: the schedule solve() uses for this workspace */
 
 #ifdef __cplusplus

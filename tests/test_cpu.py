@@ -1,6 +1,7 @@
 """CPU-only tests (no GPU): the oracle against the golden fixtures produced by the reference, the host-side
 logic (sharding, descriptors, the drop-in classes' argument handling) and the C-ABI library's exported symbols."""
 import ctypes
+import time
 import os
 import re
 import subprocess
@@ -256,6 +257,27 @@ def test_shard_ranges_cover_the_batch():
         assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
         sizes = [h - l for l, h in rs]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_launcher_starts_one_process_per_rank(tmp_path):
+    """`python bench.py --gpus N` outside torchrun starts its own N ranks: each child gets the environment
+    torch.distributed.run would give it; rank 0 owns stdout; a failing rank takes the others down instead of leaving
+    them waiting in the rendezvous"""
+    import bench
+    script = ('import os, sys; e = os.environ; open(os.path.join(%r, "rank" + e["RANK"]), "w").write(" ".join('
+              'e[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))); '
+              'print("hello from", e["RANK"])') % str(tmp_path)
+    with open(tmp_path / 'out0', 'w') as out0:
+        codes = bench.spawn_ranks(3, [sys.executable, '-c', script], rank0_stdout=out0)
+    assert codes == [0, 0, 0]
+    rows = [open(tmp_path / ('rank%d' % r)).read().split() for r in range(3)]
+    assert [r[:5] for r in rows] == [[str(i), str(i), '3', '3', '127.0.0.1'] for i in range(3)]
+    assert len({r[5] for r in rows}) == 1 and int(rows[0][5]) > 0
+    assert open(tmp_path / 'out0').read() == 'hello from 0\n'           # only rank 0 writes to the launcher's stdout
+    t0 = time.time()
+    bad = 'import os, sys, time\nif os.environ["RANK"] == "1": sys.exit(3)\ntime.sleep(120)'
+    codes = bench.spawn_ranks(3, [sys.executable, '-c', bad])
+    assert codes[1] == 3 and codes[0] != 0 and codes[2] != 0 and time.time() - t0 < 60
 
 
 WORKER = r'''

@@ -7,6 +7,8 @@ access pattern (8 B per lane, 512-byte rows): k_cost reads B*N*m*8 bytes of U an
 k_rollout's WRITE_SIZE matches the bytes of X and U it writes exactly.  For k_linesearch (W lanes share one 8-byte
 address) the factor is an upper bound: narrow requests may be tallied at their true size."""
 import csv, glob, json, os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_hash       # hash of the kernel sources the counters were taken on (bench.py drops stale traffic)
 
 def short(name):
     for k in ('k_linesearch', 'k_riccati_grp', 'k_riccati_quad', 'k_riccati', 'k_accept_par', 'k_accept_lin', 'k_save_boundaries', 'k_linearize', 'k_rollout', 'k_cost', 'k_backward', 'k_forward', 'k_ltvlqr'):
@@ -47,7 +49,7 @@ def main():
                     cfg = json.loads(line[7:])
         tr = {'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_probe.py (tools/collect_profiles.sh); '
                         'bytes per kernel launch, FETCH_SIZE x2 (gfx950), a line-search pass is one launch per round',
-              'config': cfg,
+              'config': cfg, 'source_hash': source_hash(),
               'kernels': {k: {'hbm_bytes_per_launch': v['hbm_bytes_per_launch'], 'read': v['hbm_read_bytes_per_launch'],
                               'write': v['hbm_write_bytes_per_launch'], 'launches': v['launches']}
                           for k, v in out.items() if 'hbm_bytes_per_launch' in v}}
