@@ -15,7 +15,9 @@ SYSTEM_IDS = {'pendulum': 0, 'acrobot': 1, 'cartpole': 2, 'quadcopter': 3, 'car'
               'double_pendulum': 6}
 DEFAULT_OPTS = (0.95, 0.05, 1e-3, 0.1)   # ilqr.py:166-169
 
+_SO_FMA = os.path.join(_HERE, 'libilqr_oracle_fma.so')
 _lib = None
+_lib_fma = None
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 
@@ -32,6 +34,17 @@ def lib():
         _lib = C.CDLL(_SO)
         _lib.oracle_cost.restype = C.c_double
     return _lib
+
+
+def lib_fma():
+    """the oracle rebuilt WITH fused multiply-adds (oracle/Makefile): last-bit rounding differs, nothing else -- used only
+    to measure how far a problem amplifies rounding (the noise floor of a GPU-vs-oracle comparison)"""
+    global _lib_fma
+    if _lib_fma is None:
+        if not os.path.exists(_SO_FMA):
+            build()
+        _lib_fma = C.CDLL(_SO_FMA)
+    return _lib_fma
 
 
 def _d(a):
@@ -106,8 +119,8 @@ def forward(system, init_state, ref_states, ref_inputs, k, K, learning_rate, dt,
 
 
 def solve_batched(system, init_state, target, guess, Qk, Rk, QT, dt, params, n_iterations, opts=DEFAULT_OPTS,
-                  zero_first=True, n_threads=0, want_trace=True):
-    """init_state (B,n), guess (B,N,m), target (n,) or (B,n), params (P,) or (B,P)."""
+                  zero_first=True, n_threads=0, want_trace=True, fma=False):
+    """init_state (B,n), guess (B,N,m), target (n,) or (B,n), params (P,) or (B,P).  fma: the FMA-contracted build."""
     n, m, npar = dims(system)
     init_state, guess = _d(init_state).reshape(-1, n), _d(guess)
     B, N = guess.shape[0], guess.shape[1]
@@ -119,7 +132,7 @@ def solve_batched(system, init_state, target, guess, Qk, Rk, QT, dt, params, n_i
     cost_ = np.empty(B); iters = np.empty(B, np.int32); status = np.empty(B, np.int32)
     trace = np.empty((B, n_iterations, 6)) if want_trace else None
     o = _d(opts)
-    rc = lib().oracle_solve_batched(SYSTEM_IDS[system], C.c_int64(B), N, _p(init_state), _p(target), C.c_int64(ts),
+    rc = (lib_fma() if fma else lib()).oracle_solve_batched(SYSTEM_IDS[system], C.c_int64(B), N, _p(init_state), _p(target), C.c_int64(ts),
                                     _p(guess), _p(_d(Qk)), _p(_d(Rk)), _p(_d(QT)), C.c_double(dt), _p(params),
                                     C.c_int64(ps), int(n_iterations), _p(o), int(zero_first), _p(states), _p(inputs),
                                     _p(k), _p(K), _p(cost_), iters.ctypes.data_as(_ip), status.ctypes.data_as(_ip),

@@ -26,6 +26,26 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b))) / den
 
 
+def elem_err(a, b, floor_frac=1e-3):
+    """max over ELEMENTS of |a-b| / max(|b|, floor_frac * max|b|): every entry is judged on its own scale, down to an
+    absolute floor (entries smaller than floor_frac of the largest one are rounding residue of sums of larger terms and
+    are judged against that floor).  rel_err above is norm-wise and hides errors in the small entries of an array whose
+    entries span orders of magnitude (gains K: 1e-1 ... 1e2); this one does not."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    den = np.maximum(np.abs(b), max(floor_frac * float(np.max(np.abs(b))), 1e-300))
+    return float(np.max(np.abs(a - b) / den))
+
+
+# element-wise bar for the gains of one teacher-forced backward pass.  n <= 4: the 1e-8 of the north star.  Quadcopter:
+# the CPU oracle -- bit-identical dynamics, LU inverse like numpy -- is itself 4.6e-8 from numpy on this measure (numpy's
+# 12 x 12 products go through OpenBLAS dgemm, another summation order), the GPU (Cholesky-based inverse, fused products)
+# 1.7e-7; in both cases the difference sits in entries at the floor (|K| ~ 1e-10 where the hover symmetry makes the exact
+# value 0: absolute error 1e-9 on gains of size 7, 1.7e-10 norm-wise).
+def elem_tol(system):
+    return 5e-7 if system == 'quadcopter' else 1e-8
+
+
 @pytest.fixture(scope='session')
 def oracle():
     from oracle import oracle as O

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, golden, rel_err
+from conftest import ROOT, elem_err, elem_tol, golden, rel_err
 
 SYSTEMS = ['pendulum', 'acrobot', 'cartpole', 'quadcopter', 'car', 'double_integrator', 'double_pendulum']
 KAT_SYSTEMS = ['pendulum', 'acrobot', 'cartpole', 'quadcopter', 'car']     # systems with a MATLAB *-trajectory.mat
@@ -44,6 +44,7 @@ def test_oracle_single_passes(oracle, system):
     assert abs(oracle.cost(st, u, p['Rk'], p['QT'], p['target']) - float(p['cost0'])) <= 1e-13 * abs(float(p['cost0']))
     k, K, dJ = oracle.backward(system, p['states0'], p['inputs0'], p['target'], p['Qk'], p['Rk'], p['QT'], dt, p['params'])
     assert rel_err(k, p['k']) < 1e-9 and rel_err(K, p['K']) < 1e-9 and rel_err(dJ, p['dJ']) < 1e-10
+    assert elem_err(K, p['K']) < elem_tol(system) and elem_err(k, p['k']) < elem_tol(system)      # entry by entry
     stride = int(p['fwd_stride'])
     for i, a in enumerate(p['alphas']):
         fs, fu = oracle.forward(system, p['init'], p['states0'], p['inputs0'], p['k'], p['K'], float(a), dt, p['params'])
@@ -257,6 +258,34 @@ def test_shard_ranges_cover_the_batch():
         assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
         sizes = [h - l for l, h in rs]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_headline_batch_rounding_noise_floor(oracle):
+    """How far do the random swing-ups of the bench workload (BASELINE configs[1]) amplify last-bit rounding?  The oracle
+    against ITSELF built with fused multiply-adds (oracle/Makefile: nothing but last-bit rounding differs) on the first 512
+    problems, 10 iterations: every line-search decision (ilqr.py:185-202) is the same, the final costs are not -- median
+    ~4e-11, p90 ~3e-9, p99 ~1e-7, max ~2e-6, ~96 % within 1e-8, growing ~3-10x per iteration on the worst problems.
+    That spread is a property of the problems, and the floor the GPU-vs-oracle comparison on the full batch
+    (tests/test_gpu_fullsize.py::test_c2_every_problem_against_the_oracle) is judged against."""
+    import bench
+    cfg = bench.acrobot_c2(4096, seed=0)
+    S = 512
+    a, b = (oracle.solve_batched('acrobot', cfg['init'][:S], cfg['target'], cfg['guess'][:S], cfg['Qk'], cfg['Rk'], cfg['QT'], cfg['dt'],
+                                 cfg['params'], 10, fma=fma) for fma in (False, True))
+    assert np.array_equal(a['trace'][:, :, 4], b['trace'][:, :, 4], equal_nan=True)      # accepted trial of every search
+    assert np.array_equal(a['status'], b['status']) and np.array_equal(a['iters'], b['iters'])
+    d = np.abs(a['cost'] - b['cost']) / np.abs(a['cost'])
+    q50, q90, q99, qmax = np.quantile(d, [0.5, 0.9, 0.99, 1.0])
+    assert 1e-13 < q50 < 1e-9 and q90 < 1e-7 and q99 < 1e-5 and qmax < 1e-3, (q50, q90, q99, qmax)
+    assert 0.9 < np.mean(d <= 1e-8) < 1.0             # the 1e-8 bar is met by most, not all: an amplified rounding difference
+    # the amplification is visible iteration by iteration: the median distance after iteration 9 is > 100x that after iteration 0
+    per_it = [np.nanmedian(np.abs(a['trace'][:, it, 5] - b['trace'][:, it, 5]) / np.abs(a['trace'][:, it, 5])) for it in (0, 9)]
+    assert per_it[1] > 100 * per_it[0] > 0
+    # problem 0 is the reference's own example: the reference itself after 10 iterations (tools/make_golden.py solve10)
+    g = golden('acrobot_solve10')
+    assert np.array_equal(a['trace'][0, :, 4], g['trace'][:, 4])
+    assert rel_err(a['states'][0], g['states']) < TOL and rel_err(a['K'][0], g['K']) < TOL and rel_err(a['inputs'][0], g['inputs']) < TOL
+    assert abs(a['cost'][0] - float(g['cost'])) <= TOL * abs(float(g['cost']))
 
 
 def test_bench_launcher_starts_one_process_per_rank(tmp_path):

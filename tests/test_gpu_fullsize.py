@@ -11,7 +11,7 @@ The CPU oracle cannot solve 10^5 problems in seconds, so at these sizes parity i
 import numpy as np
 import pytest
 
-from conftest import golden, rel_err
+from conftest import elem_err, golden, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-8
@@ -122,6 +122,57 @@ def test_c2_acrobot_4096(amd, oracle):
     assert np.array_equal(ws2.download(_lib.F_TRACE), trace[sub], equal_nan=True)
 
 
+def quantiles(d):
+    return np.quantile(d, [0.5, 0.9, 0.99, 1.0])
+
+
+def test_c2_every_problem_against_the_oracle(amd, oracle):
+    """The whole headline batch (4096 problems, 10 iterations) against the CPU oracle, problem by problem.
+    * Decisions are discrete and must agree EXACTLY: the accepted trial of every line search of every problem
+      (ilqr.py:185-202), exit status and iteration count.
+    * Values: problem 0 -- the reference's own example -- within 1e-8 of the REFERENCE after 10 iterations (fixture
+      acrobot_solve10.npz) on states, inputs, gains and cost.  Over the whole batch the random swing-ups amplify last-bit
+      rounding ~3-10x per iteration (tests/test_cpu.py::test_headline_batch_rounding_noise_floor): the bar is the
+      distance of the oracle from ITSELF rebuilt with fused multiply-adds, measured here on the same 4096 problems --
+      the GPU may sit no further from the oracle than that noise floor (quantile by quantile, with the slack two samples
+      of one heavy-tailed distribution need: 4x at the median / p90, 6x at p99, 30x at the maximum)."""
+    import bench
+    from ilqr_amd import _lib
+    cfg = bench.acrobot_c2(4096, seed=0)
+    ws = solve_ws(amd, 'acrobot', cfg, cfg['init'], cfg['guess'], cfg['target'], 10)
+    trace, status, iters, cost = (ws.download(f) for f in (_lib.F_TRACE, _lib.F_STATUS, _lib.F_ITERS, _lib.F_COST))
+    states, inputs, K = (ws.download(f) for f in (_lib.F_STATES, _lib.F_INPUTS, _lib.F_KFB))
+    args = ('acrobot', cfg['init'], cfg['target'], cfg['guess'], cfg['Qk'], cfg['Rk'], cfg['QT'], cfg['dt'], cfg['params'], 10)
+    o = oracle.solve_batched(*args)
+    assert np.array_equal(trace[:, :, 4], o['trace'][:, :, 4], equal_nan=True)
+    assert np.array_equal(status, o['status']) and np.array_equal(iters, o['iters'])
+    g = golden('acrobot_solve10')
+    assert np.array_equal(trace[0, :, 4], g['trace'][:, 4])
+    assert rel_err(states[0], g['states']) < TOL and rel_err(inputs[0], g['inputs']) < TOL and rel_err(K[0], g['K']) < TOL
+    assert elem_err(K[0], g['K']) < 1e-6            # entry by entry: 10 iterations amplify ~100x what one pass shows (1e-8)
+    assert abs(cost[0] - float(g['cost'])) <= TOL * abs(float(g['cost']))
+    f = oracle.solve_batched(*args, fma=True)
+    assert np.array_equal(f['trace'][:, :, 4], o['trace'][:, :, 4], equal_nan=True)
+    slack = np.array([4.0, 4.0, 6.0, 30.0])
+
+    def dist(a, b):                                  # per problem, norm-wise as rel_err
+        ax = tuple(range(1, a.ndim))
+        return np.max(np.abs(a - b), axis=ax) / np.max(np.abs(b), axis=ax) if ax else np.abs(a - b) / np.abs(b)
+
+    report = {}
+    for name, gpu, ora, fma in (('cost', cost, o['cost'], f['cost']), ('states', states, o['states'], f['states']),
+                                ('inputs', inputs, o['inputs'], f['inputs']), ('K', K, o['K'], f['K'])):
+        q_gpu, q_floor = quantiles(dist(gpu, ora)), quantiles(dist(fma, ora))
+        report[name] = (q_gpu, q_floor)
+        assert np.all(q_gpu <= slack * q_floor), (name, q_gpu, q_floor)
+    # the curve, iteration by iteration: median distance of the accepted costs, GPU vs oracle against the floor
+    for it in range(10):
+        d_gpu = np.abs(trace[:, it, 5] - o['trace'][:, it, 5]) / np.abs(o['trace'][:, it, 5])
+        d_flr = np.abs(f['trace'][:, it, 5] - o['trace'][:, it, 5]) / np.abs(o['trace'][:, it, 5])
+        assert np.nanmedian(d_gpu) <= 4.0 * np.nanmedian(d_flr) + 1e-15, it
+    print('C2 GPU-vs-oracle | oracle-vs-oracle(FMA) quantiles [50, 90, 99, 100]:', {k_: [list(np.round(v, 13)) for v in vv] for k_, vv in report.items()})
+
+
 def test_c3_ltvlqr_65536(amd, oracle):
     """configs[2]: ltvlqr gain schedules for 65 536 perturbed copies of the reference's acrobot_swingup_*.csv trajectory"""
     from ilqr_amd import _lib
@@ -169,6 +220,31 @@ def test_c4_cartpole_131072(amd, oracle):
     assert cost[5] == cost[100000] and np.array_equal(trace[5], trace[100000], equal_nan=True)
     # cartpole amplifies rounding ~10x per iteration: compare the first iterations only
     compare_sample_with_oracle(oracle, 'cartpole', g, init, guess, g['target'], ws, [0, 64, 131071], 3)
+    # ... and measure that amplification instead of asserting it: the first 512 problems through all 10 iterations against
+    # the oracle, with the oracle-vs-oracle(FMA) pair as the noise floor (see test_c2_every_problem_against_the_oracle).
+    # The floor pair itself agrees on every line-search decision up to iteration ~8 and flips about one problem in 500
+    # after that (a flipped decision is an O(1) divergence from there on), so: identical decisions for every problem
+    # through iteration 5, flips after that no more frequent than the floor's (4x + 2 problems), and the median cost
+    # distance per iteration within 4x of the floor's curve (1e-14, 4e-13, 1e-11, 8e-11, 6e-10, 3e-9, ... 2e-7 at 10).
+    S = 512
+    args = ('cartpole', init[:S], g['target'], guess[:S], g['Qk'], g['Rk'], g['QT'], float(g['dt']), g['params'], 10)
+    o, f = oracle.solve_batched(*args), oracle.solve_batched(*args, fma=True)
+
+    def same(a, b):
+        return (a == b) | (np.isnan(a) & np.isnan(b))
+
+    dec_gpu, dec_flr = same(trace[:S, :, 4], o['trace'][:, :, 4]), same(f['trace'][:, :, 4], o['trace'][:, :, 4])
+    assert dec_gpu[:, :6].all(), np.argwhere(~dec_gpu[:, :6])[:5]
+    assert (~dec_gpu.all(1)).sum() <= 4 * (~dec_flr.all(1)).sum() + 2, ((~dec_gpu.all(1)).sum(), (~dec_flr.all(1)).sum())
+    curve = []
+    for it in range(10):
+        ok = dec_gpu[:, :it + 1].all(1) & dec_flr[:, :it + 1].all(1)           # same decisions so far: the same sequence of steps
+        d_gpu = (np.abs(trace[:S, it, 5] - o['trace'][:, it, 5]) / np.abs(o['trace'][:, it, 5]))[ok]
+        d_flr = (np.abs(f['trace'][:, it, 5] - o['trace'][:, it, 5]) / np.abs(o['trace'][:, it, 5]))[ok]
+        curve.append((float(np.nanmedian(d_gpu)), float(np.nanmedian(d_flr))))
+        assert curve[-1][0] <= 4.0 * curve[-1][1] + 1e-15, (it, curve[-1])
+    assert curve[0][0] < 1e-12 and curve[2][0] < TOL                          # 1e-8 holds for the first iterations
+    print('C4 median cost distance per iteration, GPU-vs-oracle | oracle-vs-oracle(FMA):', [tuple(np.round(c, 14)) for c in curve])
 
 
 def test_c5_quadcopter_32768(amd, oracle):

@@ -8,7 +8,7 @@ Bar (BASELINE.json north_star): 1e-8 relative on cost, states, inputs and gains,
 import numpy as np
 import pytest
 
-from conftest import golden, rel_err
+from conftest import elem_err, elem_tol, golden, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -86,6 +86,7 @@ def test_backward_pass_teacher_forced(amd, system):
     k, K, dj = s.backwards_pass()
     assert rel_err(k, p['k']) < TOL
     assert rel_err(K, p['K']) < TOL
+    assert elem_err(K, p['K']) < elem_tol(system) and elem_err(k, p['k']) < elem_tol(system)     # entry by entry, not norm-wise
     assert abs(dj - p['dJ'][0]) <= TOL * abs(p['dJ'][0])
     assert abs(s.expected_cost_reduction_grad_ - p['dJ'][1]) <= TOL * abs(p['dJ'][1])
     assert abs(s.expected_cost_reduction_hess_ - p['dJ'][2]) <= TOL * abs(p['dJ'][2])

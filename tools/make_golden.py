@@ -19,6 +19,8 @@ Fixtures (all float64, reference numpy layout):
   <sys>_tracking.npz       the closed-loop simulation the two *_ltvlqr_tracking.py examples run with those gains from a
                            perturbed initial state (their own perturbation + a few seeded ones), reference f
   <sys>_batch.npz          8 seeded problems, short horizon, n_iterations=3, solved one by one
+  acrobot_solve10.npz      the acrobot example stopped after 10 iterations (the bench's fixed iteration count; problem 0 of
+                           the headline batch): `python tools/make_golden.py solve10`
 """
 import contextlib
 import io
@@ -346,6 +348,12 @@ def gen_ltvlqr(fabs, pend_solve):
 
 def main():
     only = set(sys.argv[1:])
+    if only == {'solve10'}:           # the acrobot example with n_iterations = 10 (BASELINE configs[1] runs 10 iterations)
+        c = dict(CONFIG['acrobot'](), n_iterations=10)
+        r = run_solve(make(c, lambdified('acrobot')))
+        print('  acrobot, 10 iterations: status %d, cost %.16g' % (r['status'], r['cost']))
+        save('acrobot_solve10', **cfg_arrays(c), **r)
+        return
     fabs = {}
     for name in models.BUILDERS:
         fabs[name] = lambdified(name)
