@@ -72,15 +72,20 @@ def pendulum():
     return _finish('pendulum', states, inputs, dt, Matrix([m, g, L]), f)
 
 
-def acrobot():
+def _two_link_arm(name, both_joints_actuated):
+    """The planar two-link arm of symbolic_dynamics.py:31-77 (manipulator equation M(q) q_ddot + C q_dot + N = Y through body
+    Jacobians and Christoffel symbols), with the torque on the second joint only (the reference's acrobot) or on both
+    joints (matlab/smooth-ilqr/symbolic_dynamics_double_pendulum.m:3-58).  The reference returns only lambdified callables,
+    so reproducing its expression tree -- which the generated code must match literal for literal -- means building the
+    expressions in the same sequence."""
     q1, q2, q1_dot, q2_dot = sp.symbols('q1 q2 q1_dot q2_dot')
-    tau_2 = sp.symbols('tau_2')
+    tau_1, tau_2 = sp.symbols('tau_1 tau_2')
     m1, L1, m2, L2, g, dt = sp.symbols('m1 L1 m2 L2 g dt ')
     q = Matrix([[q1], [q2]])
     q_dot = Matrix([[q1_dot], [q2_dot]])
-    tau = Matrix([[0], [tau_2]])
+    tau = Matrix([[tau_1 if both_joints_actuated else 0], [tau_2]])
     states = Matrix([[q], [q_dot]])
-    inputs = Matrix([tau_2])
+    inputs = Matrix([tau_1, tau_2]) if both_joints_actuated else Matrix([tau_2])
     # generalised inertia of each link (python float 1/12 on purpose: it becomes a sympy Float)
     M1 = Matrix([[m1, 0, 0], [0, m1, 0], [0, 0, 1 / 12 * m1 * L1 * L1]])
     M2 = Matrix([[m2, 0, 0], [0, m2, 0], [0, 0, 1 / 12 * m2 * L2 * L2]])
@@ -99,7 +104,11 @@ def acrobot():
     N = V.jacobian(q).T
     Y = tau
     f = Matrix([q_dot, M.inv() @ (Y - N - C @ q_dot)])
-    return _finish('acrobot', states, inputs, dt, Matrix([m1, L1, m2, L2, g]), f)
+    return _finish(name, states, inputs, dt, Matrix([m1, L1, m2, L2, g]), f)
+
+
+def acrobot():
+    return _two_link_arm('acrobot', both_joints_actuated=False)
 
 
 def cartpole():
@@ -171,31 +180,8 @@ def double_integrator():
 
 def double_pendulum():
     """spec: matlab/smooth-ilqr/symbolic_dynamics_double_pendulum.m:3-58 -- the acrobot's two links with BOTH joints
-    actuated (tau = [tau_1; tau_2]); built with the same sequence as acrobot() above."""
-    q1, q2, q1_dot, q2_dot = sp.symbols('q1 q2 q1_dot q2_dot')
-    tau_1, tau_2 = sp.symbols('tau_1 tau_2')
-    m1, L1, m2, L2, g, dt = sp.symbols('m1 L1 m2 L2 g dt ')
-    q = Matrix([[q1], [q2]])
-    q_dot = Matrix([[q1_dot], [q2_dot]])
-    tau = Matrix([[tau_1], [tau_2]])
-    states = Matrix([[q], [q_dot]])
-    inputs = Matrix([tau_1, tau_2])
-    M1 = Matrix([[m1, 0, 0], [0, m1, 0], [0, 0, 1 / 12 * m1 * L1 * L1]])
-    M2 = Matrix([[m2, 0, 0], [0, m2, 0], [0, 0, 1 / 12 * m2 * L2 * L2]])
-    Jb_sL1 = Matrix([[0, 0], [L1 / 2, 0], [1, 0]])
-    Jb_sL2 = Matrix([[L1 * sp.sin(q2), 0], [L1 * sp.cos(q2) + L2 / 2, L2 / 2], [1, 1]])
-    M = sp.simplify(Jb_sL1.T @ M1 @ Jb_sL1 + Jb_sL2.T @ M2 @ Jb_sL2)
-    nq = 2
-    C = sp.zeros(nq, nq)
-    for ii in range(nq):
-        for jj in range(nq):
-            for kk in range(nq):
-                C[ii, jj] = C[ii, jj] + 1 / 2 * (sp.diff(M[ii, jj], q[kk]) + sp.diff(M[ii, kk], q[jj])
-                                                 - sp.diff(M[jj, kk], q[ii])) * q_dot[kk]
-    V = Matrix([(m1 * g * L1 / 2 * sp.sin(q1) + m2 * g * (L1 * sp.sin(q1) + L2 / 2 * sp.sin(q1 + q2)))])
-    N = V.jacobian(q).T
-    f = Matrix([q_dot, M.inv() @ (tau - N - C @ q_dot)])
-    return _finish('double_pendulum', states, inputs, dt, Matrix([m1, L1, m2, L2, g]), f)
+    actuated (tau = [tau_1; tau_2])"""
+    return _two_link_arm('double_pendulum', both_joints_actuated=True)
 
 
 BUILDERS = {'pendulum': pendulum, 'acrobot': acrobot, 'cartpole': cartpole, 'quadcopter': quadcopter, 'car': car,
