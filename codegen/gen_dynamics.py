@@ -225,7 +225,61 @@ def _function(model, what, mat):
             lines.append('    out[%d] = %s;' % (k, e))
             k += 1
     lines.append('}')
+    if what == 'f':
+        lines += _function_f_sc(model, em, els, sums)
     return '\n'.join(lines), src
+
+
+def _function_f_sc(model, em, els, sums):
+    """f once more, for the time-step loops: sin/cos of the angles that are plain state components (x[i]) are NOT
+    evaluated here but handed in by the caller in `sc` (pair k = sin, cos of state component f_ang[k]), who carries them
+    from step to step by angle addition on the step's exact increment (kernels_common.h TrigCarry) instead of a fresh
+    range reduction + two polynomial kernels per step.  Sums of two such angles keep the sum formula; any other argument
+    is evaluated as in f.  Same expression tree otherwise."""
+    up = model.name.upper()
+    carried = []                       # (state index, pair index i) in order of first use
+    for arg, i in em.trig_args:
+        m = re.fullmatch(r'x\[(\d+)\]', arg)
+        if m and i not in sums:
+            carried.append((int(m.group(1)), i))
+    slot = {i: k for k, (_, i) in enumerate(carried)}
+    lines = ['', '#define ILQR_DYN_%s_F_NANG %d' % (up, len(carried)),
+             '/* state components whose sin/cos pair the caller of f_sc carries */',
+             'ILQR_DYN_CONST int ilqr_dyn_%s_f_ang[%d] = {%s};' % (model.name, max(len(carried), 1),
+                                                                    ', '.join(str(a) for a, _ in carried) or '0'),
+             'ILQR_DYN_FN void ilqr_dyn_%s_f_sc(const double* x, const double* u, const double dt, const double* p, '
+             'const double* sc, double* out)' % model.name, '{', '    ILQR_DYN_F_PROLOGUE',
+             '    (void)x; (void)u; (void)dt; (void)p; (void)sc;']
+    direct = []
+    for arg, i in em.trig_args:
+        if i in slot:
+            lines.append('    const double sn%d = sc[%d], cs%d = sc[%d]; (void)sn%d; (void)cs%d;' % (i, 2 * slot[i], i, 2 * slot[i] + 1, i, i))
+        elif i not in sums:
+            lines.append('    double sn%d, cs%d; ILQR_DYN_SINCOS(%s, sn%d, cs%d); (void)sn%d; (void)cs%d;' % (i, i, arg, i, i, i, i))
+            direct.append((arg, i))
+    for i, (a, ia, b, ib) in sorted(sums.items()):
+        lines.append('    double sn%d, cs%d; ILQR_DYN_SINCOS_SUM(%s, %s, sn%d, cs%d, sn%d, cs%d, sn%d, cs%d); (void)sn%d; (void)cs%d;'
+                     % (i, i, a, b, ia, ia, ib, ib, i, i, i, i))
+    if direct:
+        lines.append('    if (%s) {' % ' || '.join('ILQR_DYN_TRIG_BIG(%s)' % a for a, i in direct))
+        for a, i in direct:
+            lines.append('        ILQR_DYN_SINCOS_SLOW(%s, sn%d, cs%d);' % (a, i, i))
+        lines.append('    }')
+    pair = dict(em.trig_args)
+    for i, arg in em.tan_defs:
+        if arg in pair:
+            lines.append('    const double tn%d = ILQR_DYN_TAN_SC(%s, sn%d, cs%d);' % (i, arg, pair[arg], pair[arg]))
+        else:
+            lines.append('    const double tn%d = ILQR_DYN_TAN(%s);' % (i, arg))
+    for d in em.rcp_defs:
+        lines.append('    ' + d)
+    k = 0
+    for row in els:
+        for e in row:
+            lines.append('    out[%d] = %s;' % (k, e))
+            k += 1
+    lines.append('}')
+    return lines
 
 
 def generate(name):

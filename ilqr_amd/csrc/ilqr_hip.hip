@@ -1358,6 +1358,7 @@ extern "C" int ltvlqr_device_noalloc(const ilqr_desc* d, int32_t n_state_rows, c
     w.state_rows = w.N + 1;
     w.stream = (hipStream_t)stream;
     w.n_sub = 1;
+    w.ck = CKPT_INTERVAL;
     w.grp = w.n > 4;                                    // as ilqr_ws_create: P of n > 4 does not fit one lane
     w.n_lin = with_system(d->system_id, [&](auto S) { return Lin<decltype(S)>::n_lin; });
     const size_t Bp = (size_t)w.Bpad, n = w.n, m = w.m, np = w.np, N = w.N;

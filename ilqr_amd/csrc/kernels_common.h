@@ -12,10 +12,19 @@ constexpr int N_KERNEL_IDS = 8;
 #ifndef ILQR_LIN_SKIP_DT
 #define ILQR_LIN_SKIP_DT 1
 #endif
-#define ILQR_DEFINE_SYSTEM(NAME, UP)                                                                              \
+#ifndef ILQR_TRIG_CARRY
+#define ILQR_TRIG_CARRY 1
+#endif
+#define ILQR_DEFINE_SYSTEM(NAME, UP, CARRY)                                                                       \
     struct Sys_##NAME {                                                                                           \
         static constexpr int n = ILQR_DYN_##UP##_N, m = ILQR_DYN_##UP##_M, np = ILQR_DYN_##UP##_NP;               \
         static constexpr int id = ILQR_DYN_##UP##_ID;                                                             \
+        /* time-step loops carry the sin/cos pairs of these state components from step to step (TrigCarry) */     \
+        static constexpr int n_ang = (ILQR_TRIG_CARRY && (CARRY)) ? ILQR_DYN_##UP##_F_NANG : 0;                   \
+        static __device__ __forceinline__ int ang(int k) { return ilqr_dyn_##NAME##_f_ang[k]; }                   \
+        static __device__ __forceinline__ void f_sc(const double* x, const double* u, double dt, const double* p, \
+                                                    const double* sc, double* o)                                  \
+        { ilqr_dyn_##NAME##_f_sc(x, u, dt, p, sc, o); }                                                           \
         static constexpr const char* A_pat = ilqr_dyn_##NAME##_A_pat;                                             \
         static constexpr const char* B_pat = ilqr_dyn_##NAME##_B_pat;                                             \
         static __device__ __forceinline__ char a_kind(int i) { return ilqr_dyn_##NAME##_A_pat[i]; }               \
@@ -34,13 +43,13 @@ constexpr int N_KERNEL_IDS = 8;
         static __device__ __forceinline__ void B(const double* x, const double* u, double dt, const double* p,   \
                                                  double* o) { ilqr_dyn_##NAME##_B(x, u, dt, p, o); }              \
     };
-ILQR_DEFINE_SYSTEM(pendulum, PENDULUM)
-ILQR_DEFINE_SYSTEM(acrobot, ACROBOT)
-ILQR_DEFINE_SYSTEM(cartpole, CARTPOLE)
-ILQR_DEFINE_SYSTEM(quadcopter, QUADCOPTER)
-ILQR_DEFINE_SYSTEM(car, CAR)
-ILQR_DEFINE_SYSTEM(double_integrator, DOUBLE_INTEGRATOR)
-ILQR_DEFINE_SYSTEM(double_pendulum, DOUBLE_PENDULUM)
+ILQR_DEFINE_SYSTEM(pendulum, PENDULUM, 1)
+ILQR_DEFINE_SYSTEM(acrobot, ACROBOT, 1)
+ILQR_DEFINE_SYSTEM(cartpole, CARTPOLE, 1)
+ILQR_DEFINE_SYSTEM(quadcopter, QUADCOPTER, !ILQR_QUAD_TRIG_LIB)   // library trig (parity margin, ilqr_hip.hip): nothing to carry
+ILQR_DEFINE_SYSTEM(car, CAR, 1)
+ILQR_DEFINE_SYSTEM(double_integrator, DOUBLE_INTEGRATOR, 1)
+ILQR_DEFINE_SYSTEM(double_pendulum, DOUBLE_PENDULUM, 1)
 
 struct SysInfo { const char* name; int n, m, np; };
 constexpr int N_SYSTEMS = 7;
@@ -101,6 +110,61 @@ struct KArgs {
     int* accepts;
     double* trace;         // [tile][n_iter][6][64] or nullptr
     long long Bpad;
+};
+
+// ------------------------------------------------------------------------------------------------
+// TrigCarry: sin/cos of the angle states, carried along a rollout instead of evaluated afresh every step.
+// A rollout step changes an angle by d = x_{t+1} - x_t, a few 1e-3 rad (dt * velocity): sin and cos of the new angle follow
+// from the old pair by angle addition with sin d, cos d - 1 from short Taylor polynomials -- ~20 fp64 instructions per
+// angle instead of ~55 (range reduction, two minimax kernels, quadrant selects); the acrobot's line-search step drops
+// from ~265 to ~195 instructions.
+//   * d is formed by one subtraction: its rounding error is 2^-53 |d| ~ 1e-19, far below the pair's own rounding.
+//   * |d| <= 2^-4: the neglected Taylor terms are d^11/11! < 2e-21 (sin) and d^10/10! < 3e-19 (cos).  The update is
+//     written s + (small), c + (small): ONE rounding of the pair per step (half an ulp), i.e. a random walk of a few ulp
+//     between re-seeds -- and in f every trig value is scaled by dt before it meets the state (<= 1e-18 of an O(1) state
+//     per step: below the rounding of the state update itself).
+//   * re-seeded with the full evaluation (ilqr_sincos_fast; ocml for huge / non-finite angles) at every multiple of the
+//     checkpoint interval -- so a rollout resumed from a line-search checkpoint (k_accept_lin) sees exactly the pairs
+//     the trial saw: same bits whichever kernel, schedule or segment computes a step -- and at once for any lane whose
+//     step is larger than 2^-4 rad or not finite (diverging trials).
+// The Jacobians A_t, B_t keep their direct evaluations (their entries are not scaled against a large addend).
+// ------------------------------------------------------------------------------------------------
+template <class S>
+struct TrigCarry {
+    static constexpr int K = S::n_ang;
+    double sc[K > 0 ? 2 * K : 1];
+
+    static __device__ __forceinline__ void full(const double x, double& s, double& c)
+    {
+        ilqr_sincos_fast(x, s, c);
+        if (!(__builtin_fabs(x) < 1.0e6)) { const ilqr_sc r = ilqr_sincos_slow(x); s = r.sinv; c = r.cosv; }
+    }
+    __device__ __forceinline__ void seed(const double (&x)[S::n])
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) full(x[S::ang(k)], sc[2 * k], sc[2 * k + 1]);
+    }
+    // the pairs of xn from those of xo; reseed (uniform): evaluate afresh
+    __device__ __forceinline__ void advance(const double (&xo)[S::n], const double (&xn)[S::n], const bool reseed)
+    {
+        if constexpr (K > 0) {
+            constexpr double S1 = -1.0 / 6.0, S2 = 1.0 / 120.0, S3 = -1.0 / 5040.0, S4 = 1.0 / 362880.0;
+            constexpr double C1 = -0.5, C2 = 1.0 / 24.0, C3 = -1.0 / 720.0, C4 = 1.0 / 40320.0;
+            bool ok = !reseed;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double d = xn[S::ang(k)] - xo[S::ang(k)];
+                ok = ok && (__builtin_fabs(d) <= 0.0625);
+                const double z = d * d;
+                const double sdt = (d * z) * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S4, S3), S2), S1);   // sin d - d
+                const double cm1 = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C4, C3), C2), C1);         // cos d - 1
+                const double s = sc[2 * k], c = sc[2 * k + 1];
+                sc[2 * k] = s + __builtin_fma(c, d, __builtin_fma(c, sdt, s * cm1));
+                sc[2 * k + 1] = c + __builtin_fma(-s, d, __builtin_fma(-s, sdt, c * cm1));
+            }
+            if (!ok) seed(xn);
+        }
+    }
 };
 
 // ilqr.py:204 after the line search of one problem: accj >= 0 accepted trial (learning_rate stays alpha_accj), accj < 0

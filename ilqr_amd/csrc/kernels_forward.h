@@ -30,10 +30,20 @@ __global__ void __launch_bounds__(64) k_rollout(const KArgs a)
         store_col<n>(Xp, x0);
     }
     double cost = 0.0;
+    TrigCarry<S> trig;
+    trig.seed(x);
+    int next_seed = a.ck;
     auto one_step = [&](const int t, const double (&u)[m]) {
         double xn[n];
         cost = cost + input_cost<m>(u, Rk);
-        S::f(x, u, a.dt, p, xn);
+        if constexpr (S::n_ang > 0) {
+            S::f_sc(x, u, a.dt, p, trig.sc, xn);
+            const bool reseed = t + 1 == next_seed;
+            if (reseed) next_seed += a.ck;
+            trig.advance(x, xn, reseed);
+        } else {
+            S::f(x, u, a.dt, p, xn);
+        }
 #pragma unroll
         for (int i = 0; i < n; ++i) x[i] = xn[i];
         store_col<n>(Xp + (size_t)(t + 1) * n * TILE, x);                              // :39
@@ -138,6 +148,11 @@ __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double
         if constexpr (PREFETCH) { load_col<m * n>(Kp + (size_t)tl * (m * n) * TILE, K[d]); load_col<m>(kp + (size_t)tl * m * TILE, kf[d]); }
     }
     int next_ck = CKPT ? a.ck : 0;
+    // sin/cos pairs of the angle states, carried from step to step and evaluated afresh at every multiple of the
+    // checkpoint interval (t0 is one when this range resumes from a checkpoint): see TrigCarry
+    TrigCarry<S> trig;
+    trig.seed(x);
+    int next_seed = (t0 / a.ck + 1) * a.ck;
     auto one_step = [&](const int t, const int d, const bool refill) __attribute__((always_inline)) {
         if constexpr (!PREFETCH) {
             load_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K[d]);
@@ -185,7 +200,14 @@ __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double
             }
         }
         cost = cost + input_cost<m>(u, Rk);
-        S::f(x, u, a.dt, p, xn);                                                   // :151
+        if constexpr (S::n_ang > 0) {
+            S::f_sc(x, u, a.dt, p, trig.sc, xn);                                   // :151
+            const bool reseed = t + 1 == next_seed;
+            if (reseed) next_seed += a.ck;
+            trig.advance(x, xn, reseed);
+        } else {
+            S::f(x, u, a.dt, p, xn);                                               // :151
+        }
 #pragma unroll
         for (int i = 0; i < n; ++i) x[i] = xn[i];
         if constexpr (STORE) {

@@ -72,7 +72,9 @@ def check_properties(amd, ws, system, cfg, init, sample):
     ws.sync()
     recomputed = ws.download(_lib.F_COST)
     assert np.max(np.abs(recomputed - cost) / np.abs(cost)) < 1e-12
-    # the stored trajectory obeys the dynamics bit for bit
+    # the stored trajectory obeys the dynamics: x_{t+1} = f(x_t, u_t) re-evaluated point by point by the dynamics kernel, to
+    # the last bits (the rollouts carry the sin/cos pairs of the angle states from step to step -- TrigCarry -- where the
+    # stand-alone f evaluates them afresh: the two differ by an ulp or two of the trig values, scaled by dt in the state)
     states = ws.download(_lib.F_STATES)[sample]
     inputs = ws.download(_lib.F_INPUTS)[sample]
     f = getattr(amd, 'symbolic_dynamics_' + system)()[0]
@@ -80,7 +82,8 @@ def check_properties(amd, ws, system, cfg, init, sample):
     x_prev[:, 0] = init[sample]                                            # row 0 is stored as zero (reference quirk)
     assert np.all(states[:, 0] == 0.0)
     nxt = f.batch(x_prev.reshape(-1, states.shape[2]), inputs.reshape(-1, inputs.shape[2]), float(cfg['dt']), cfg['params'])
-    assert np.array_equal(nxt.reshape(states[:, 1:].shape), states[:, 1:])
+    nxt = nxt.reshape(states[:, 1:].shape)
+    assert np.max(np.abs(nxt - states[:, 1:]) / np.maximum(np.abs(states[:, 1:]), 1.0)) < 2e-15
     return trace, status, iters, cost
 
 
