@@ -142,6 +142,7 @@ constexpr int OVERLAP_CHUNKS = ILQR_OVERLAP_CHUNKS;   // at most; a chunk is at 
 struct ilqr_ws {
     ilqr_desc d;
     int n, m, np, N, W, n_trials, want_trace;
+    int cost_monotone;                       // R_k, Q_T diagonal and non-negative (set_weights): stage costs are >= 0 term by term
     double alpha_end;                        // the learning rate an exhausted line search ends with (ilqr.py:185,202)
     int ls_rounds_n, ls_width[MAX_TRIALS];   // line-search schedule: widths of the rounds (sum >= n_trials)
     long long B, Bpad, tiles;
@@ -177,6 +178,7 @@ KArgs make_args(ilqr_ws* ws, int it)
     a.N = ws->N; a.it = it; a.n_iter = ws->d.n_iterations; a.zero_first = ws->d.zero_first_state;
     a.n_trials = ws->n_trials; a.state_rows = ws->state_rows; a.n_tiles = ws->tiles; a.tile0 = 0;
     a.dt = ws->d.dt; a.low_red = ws->d.low_expected_reduction; a.armijo_thr = ws->d.armijo_threshold;
+    a.cost_monotone = ws->cost_monotone;
     a.quu_reg = ws->d.quu_reg; a.low_lr = ws->d.low_learning_rate; a.alpha_end = ws->alpha_end;
     a.XB = ws->XB; a.CKPT = ws->CKPT; a.LIN = ws->LIN; a.ck = ws->ck; a.n_seg = ws->n_seg;
     a.X = ws->X; a.U = ws->U; a.G = ws->G; a.KFB = ws->KFB; a.KFF = ws->KFF; a.XO = ws->X; a.UO = ws->U;
@@ -952,6 +954,15 @@ int ilqr_ws_set_weights(ilqr_ws* ws, const double* Qk, const double* Rk, const d
     if (Qk) memcpy(w.data(), Qk, n * n * 8);
     if (Rk) memcpy(w.data() + n * n, Rk, m * m * 8);
     if (QT) memcpy(w.data() + n * n + m * m, QT, n * n * 8);
+    // compute_cost (ilqr.py:56,60) adds (u'R)u per step and (d'Q_T)d at the end: with diagonal, non-negative R_k and Q_T every
+    // term is a rounded non-negative product, so the running cost of a rollout never decreases (k_linesearch uses that)
+    auto diag_nonneg = [](const double* M, size_t k) {
+        for (size_t i = 0; i < k; ++i)
+            for (size_t j = 0; j < k; ++j)
+                if (i == j ? !(M[i * k + j] >= 0.0) : M[i * k + j] != 0.0) return false;
+        return true;
+    };
+    ws->cost_monotone = diag_nonneg(w.data() + n * n, m) && diag_nonneg(w.data() + n * n + m * m, n);
     HIPCHK(hipMemcpyAsync(ws->WTS, w.data(), w.size() * 8, hipMemcpyHostToDevice, ws->stream));
     HIPCHK(hipStreamSynchronize(ws->stream));
     return 0;

@@ -99,6 +99,7 @@ struct KArgs {
     int* ls_rounds;
     int ls_round;          // line search: round r evaluates trials [ls_j0, ls_j0 + W) (W is the launched kernel's width)
     int ls_j0;
+    int cost_monotone;     // R_k and Q_T are diagonal with non-negative entries: the running cost of a rollout never decreases
     int all_problems;      // k_linearize / the ltvlqr recursion: ignore the per-problem `active` flags of solve()
     int ls_last;           // no round follows: a search that fails here has run out of learning rate
     int* ls_list;          // [2][Bpad] problems still searching after a round (ping-pong by round parity)
@@ -144,8 +145,12 @@ struct TrigCarry {
 #pragma unroll
         for (int k = 0; k < K; ++k) full(x[S::ang(k)], sc[2 * k], sc[2 * k + 1]);
     }
-    // the pairs of xn from those of xo; reseed (uniform): evaluate afresh
-    __device__ __forceinline__ void advance(const double (&xo)[S::n], const double (&xn)[S::n], const bool reseed)
+    // the pairs of xn from those of xo; reseed (uniform): evaluate afresh.  dont_care: this lane's rollout no longer
+    // matters (a line-search trial already known to fail): it keeps the recurrence whatever its step, so that it does not
+    // drag its wave through the full evaluation at every step.  A NaN step is left to the recurrence as well (NaN in, NaN
+    // out, as the full evaluation would give).
+    __device__ __forceinline__ void advance(const double (&xo)[S::n], const double (&xn)[S::n], const bool reseed,
+                                            const bool dont_care = false)
     {
         if constexpr (K > 0) {
             constexpr double S1 = -1.0 / 6.0, S2 = 1.0 / 120.0, S3 = -1.0 / 5040.0, S4 = 1.0 / 362880.0;
@@ -154,7 +159,7 @@ struct TrigCarry {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const double d = xn[S::ang(k)] - xo[S::ang(k)];
-                ok = ok && (__builtin_fabs(d) <= 0.0625);
+                ok = ok && (dont_care || !(__builtin_fabs(d) > 0.0625));
                 const double z = d * d;
                 const double sdt = (d * z) * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S4, S3), S2), S1);   // sin d - d
                 const double cm1 = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C4, C3), C2), C1);         // cos d - 1

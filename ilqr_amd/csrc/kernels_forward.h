@@ -127,8 +127,11 @@ __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double
                                                     const double* kp, double* XOp, double* UOp, double* ckp,
                                                     double (&x)[S::n], const double (&p)[S::np],
                                                     const double (&Rk)[S::m * S::m], const double alpha, const int t0,
-                                                    const int t1, const double* Xfirst = nullptr, double* Lp = nullptr)
+                                                    const int t1, const double* Xfirst = nullptr, double* Lp = nullptr,
+                                                    const double kill_at = __builtin_inf())
 {
+    // kill_at (line-search trials only, STORE = false): once the running cost exceeds it the trial is known to fail the
+    // Armijo test (k_linesearch sets it where that is provable) and the lane's remaining steps are don't-cares.
     // Xfirst: where the reference-state row of step t0 is kept when X itself is being overwritten by a neighbour
     // (k_accept_lin).  LINOUT: also evaluate A_t, B_t at the new (x_t, u_t) and store them for the next backward pass.
     constexpr int n = S::n, m = S::m;
@@ -204,7 +207,7 @@ __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double
             S::f_sc(x, u, a.dt, p, trig.sc, xn);                                   // :151
             const bool reseed = t + 1 == next_seed;
             if (reseed) next_seed += a.ck;
-            trig.advance(x, xn, reseed);
+            trig.advance(x, xn, reseed, !STORE && cost > kill_at);
         } else {
             S::f(x, u, a.dt, p, xn);                                               // :151
         }
@@ -233,9 +236,9 @@ __device__ __forceinline__ double closed_loop(const KArgs& a, const double* Xp, 
                                               const double* kp, double* XOp, double* UOp, double (&x)[S::n],
                                               const double (&p)[S::np], const double (&target)[S::n],
                                               const double (&Rk)[S::m * S::m], const double (&QT)[S::n * S::n],
-                                              const double alpha, double* ckp = nullptr)
+                                              const double alpha, double* ckp = nullptr, const double kill_at = __builtin_inf())
 {
-    double cost = closed_loop_range<S, STORE, CKPT>(a, Xp, Up, Kp, kp, XOp, UOp, ckp, x, p, Rk, alpha, 0, a.N);
+    double cost = closed_loop_range<S, STORE, CKPT>(a, Xp, Up, Kp, kp, XOp, UOp, ckp, x, p, Rk, alpha, 0, a.N, nullptr, nullptr, kill_at);
     cost = cost + terminal_cost<S::n>(x, target, QT);
     return cost;
 }
@@ -415,9 +418,16 @@ __global__ void __launch_bounds__(W == 64 ? 512 : 256, ls_waves_per_simd<S>()) k
 #pragma unroll
         for (int i = 0; i < n; ++i) x[i] = x0[i];
         double* ckp = CKPT ? a.CKPT + (size_t)b * a.n_seg * n * TILE + j : nullptr;
-        c = closed_loop<S, false, CKPT>(a, Xp, Up, Kp, kp, nullptr, nullptr, x, p, target, Rk, QT, alpha, ckp);
-        const double cost_difference = cur_cost - c;                               // :191
         const double expected = alpha * dg + (alpha * alpha) * dh;                 // :192
+        // A trial whose cost exceeds the current cost fails :193 whenever the expected reduction is positive and the
+        // threshold is not negative: (J - J_new) / expected < 0.  With R_k, Q_T diagonal and non-negative the running cost
+        // never decreases along the rollout (every stage term is a rounded R_jj u_j^2 >= 0), so once it has passed the
+        // current cost the outcome is known -- exactly, in floating point -- and the rest of the lane's rollout is a
+        // don't-care (diverging trials stop forcing the full trig evaluation on their wave; see TrigCarry::advance).
+        const bool provable = a.cost_monotone != 0 && expected > 0.0 && a.armijo_thr >= 0.0;
+        c = closed_loop<S, false, CKPT>(a, Xp, Up, Kp, kp, nullptr, nullptr, x, p, target, Rk, QT, alpha, ckp,
+                                        provable ? cur_cost : __builtin_inf());
+        const double cost_difference = cur_cost - c;                               // :191
         okj = (cost_difference / expected) > a.armijo_thr;                         // :193 (NaN -> false)
     }
     const unsigned long long mask = __ballot(okj);
