@@ -19,7 +19,7 @@ STATUS_NAMES = {0: 'max_iter', 1: 'optimal', 2: 'low_learning_rate', 3: 'numeric
 
 # fields of the device-resident workspace (include/ilqr_hip.h)
 F_INIT, F_TARGET, F_PARAMS, F_STATES, F_INPUTS, F_KFF, F_KFB, F_COST, F_DJ, F_ITERS, F_STATUS, F_TRACE, \
-    F_LS_ROUNDS, F_ACCEPTS, F_ALPHA, F_STATES_OUT, F_INPUTS_OUT, F_NEW_COST, F_GUESS = range(19)
+    F_LS_ROUNDS, F_ACCEPTS, F_ALPHA, F_STATES_OUT, F_INPUTS_OUT, F_NEW_COST, F_GUESS, F_TARGET_STATES, F_TARGET_INPUTS = range(21)
 KERNEL_NAMES = ('rollout', 'backward', 'linesearch', 'accept', 'ltvlqr', 'forward', 'cost', 'linearize')
 
 
@@ -38,7 +38,7 @@ class Desc(C.Structure):
                 ('device', C.c_int32), ('learning_speed', C.c_double), ('low_learning_rate', C.c_double),
                 ('low_expected_reduction', C.c_double), ('armijo_threshold', C.c_double), ('quu_reg', C.c_double),
                 ('target_batched', C.c_int32), ('params_batched', C.c_int32), ('pipeline', C.c_int32), ('n_streams', C.c_int32), ('riccati', C.c_int32), ('overlap', C.c_int32),
-                ('search_floor', C.c_double), ('n_devices', C.c_int32), ('device_wrap', C.c_int32)]
+                ('search_floor', C.c_double), ('n_devices', C.c_int32), ('device_wrap', C.c_int32), ('tracking', C.c_int32)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -79,6 +79,8 @@ SIGNATURES = {
     'ilqr_ws_forward': (C.c_int, [_WS, C.c_int32]),
     'ilqr_ws_solve': (C.c_int, [_WS]),
     'ilqr_ws_ltvlqr': (C.c_int, [_WS]),
+    'ilqr_ws_mpc_shift': (C.c_int, [_WS, C.c_int32]),
+    'ilqr_ws_mpc_solve': (C.c_int, [_WS, C.c_int32]),
     'ilqr_ws_sync': (C.c_int, [_WS]),
     'ilqr_ws_profile': (C.c_int, [_WS, C.c_int32]),
     'ilqr_ws_profile_read': (C.c_int, [_WS, _dp, C.POINTER(C.c_int64)]),
@@ -148,7 +150,7 @@ def system_dims(system):
 def make_desc(system, N, B, dt, n_iterations=0, n_alpha_parallel=0, zero_first_state=True, device=0,
               target_batched=False, params_batched=False, learning_speed=0.95, low_learning_rate=0.05,
               low_expected_reduction=1e-3, armijo_threshold=0.1, quu_reg=0.0, pipeline=0, n_streams=0, riccati=0, overlap=0,
-              search_floor=0.05, n_devices=0, device_wrap=False):
+              search_floor=0.05, n_devices=0, device_wrap=False, tracking=False):
     d = Desc()
     lib().ilqr_desc_default(C.byref(d))
     d.system_id = SYSTEM_IDS[system] if isinstance(system, str) else int(system)
@@ -173,6 +175,7 @@ def make_desc(system, N, B, dt, n_iterations=0, n_alpha_parallel=0, zero_first_s
     d.search_floor = float(search_floor)
     d.n_devices = int(n_devices)
     d.device_wrap = 1 if device_wrap else 0
+    d.tracking = 1 if tracking else 0
     return d
 
 
@@ -217,7 +220,8 @@ class Workspace:
                 F_PARAMS: (B, P) if self.desc.params_batched else (P,), F_STATES: (B, N + 1, n),
                 F_INPUTS: (B, N, m), F_KFF: (B, N, m), F_KFB: (B, N, m, n), F_COST: (B,), F_DJ: (B, 3), F_ITERS: (B,),
                 F_STATUS: (B,), F_TRACE: (B, self.n_iterations, 6), F_LS_ROUNDS: (B,), F_ACCEPTS: (B,), F_ALPHA: (B,),
-                F_STATES_OUT: (B, N + 1, n), F_INPUTS_OUT: (B, N, m), F_NEW_COST: (B,), F_GUESS: (B, N, m)}[field]
+                F_STATES_OUT: (B, N + 1, n), F_INPUTS_OUT: (B, N, m), F_NEW_COST: (B,), F_GUESS: (B, N, m),
+                F_TARGET_STATES: (B, N + 1, n), F_TARGET_INPUTS: (B, N, m)}[field]
 
     def set_weights(self, Qk, Rk, QT):
         n, m = self.n, self.m
@@ -259,6 +263,8 @@ class Workspace:
     def forward(self, with_cost=True): check(lib().ilqr_ws_forward(self._h, 1 if with_cost else 0))
     def solve(self): check(lib().ilqr_ws_solve(self._h))
     def ltvlqr(self): check(lib().ilqr_ws_ltvlqr(self._h))
+    def mpc_shift(self, span): check(lib().ilqr_ws_mpc_shift(self._h, int(span)))
+    def mpc_solve(self, first_call): check(lib().ilqr_ws_mpc_solve(self._h, 1 if first_call else 0))
     def sync(self): check(lib().ilqr_ws_sync(self._h))
 
     def profile(self, enable=True):

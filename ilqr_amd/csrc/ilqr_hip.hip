@@ -157,6 +157,7 @@ struct ilqr_ws {
     hipEvent_t pipe_ev[OVERLAP_CHUNKS], pipe_done;
     double* VST;
     double *X, *U, *G, *KFB, *KFF, *XO, *UO, *INIT, *TARGET, *PARAMS, *WTS, *alphas, *alpha_pp, *cost, *new_cost, *dJ, *trace;
+    double *XD, *UD;                         // tracking cost (ilqr_desc.tracking): per-step targets of the horizon window
     int *active, *iters, *status, *acc_j, *ls_rounds, *accepts, *ls_list, *ls_count;
     void* staging;
     size_t staging_bytes;
@@ -181,6 +182,7 @@ KArgs make_args(ilqr_ws* ws, int it)
     a.cost_monotone = ws->cost_monotone;
     a.quu_reg = ws->d.quu_reg; a.low_lr = ws->d.low_learning_rate; a.alpha_end = ws->alpha_end;
     a.XB = ws->XB; a.CKPT = ws->CKPT; a.LIN = ws->LIN; a.ck = ws->ck; a.n_seg = ws->n_seg;
+    a.XD = ws->XD; a.UD = ws->UD; a.fwd_to_cost = 0;
     a.X = ws->X; a.U = ws->U; a.G = ws->G; a.KFB = ws->KFB; a.KFF = ws->KFF; a.XO = ws->X; a.UO = ws->U;
     a.INIT = ws->INIT; a.TARGET = ws->TARGET; a.PARAMS = ws->PARAMS; a.WTS = ws->WTS; a.alphas = ws->alphas;
     a.alpha_pp = ws->alpha_pp; a.cost = ws->cost; a.new_cost = ws->new_cost; a.dJ = ws->dJ; a.active = ws->active;
@@ -236,12 +238,16 @@ int check_launch(const char* what)
 // W < 32 covers more).  Workgroups are dealt round-robin over the 8 XCDs, so logical neighbours (which share 128-byte
 // L2 lines) are mapped to block ids 8 apart = the same XCD's L2.  Placement is a speed matter only.
 template <class S, int W>
-void launch_ls(hipStream_t st, const KArgs& a, bool ckpt)
+void launch_ls(hipStream_t st, const KArgs& a, bool ckpt, bool track = false)
 {
     const long long waves = a.n_tiles * W;          // tiles * 64 problems * W lanes / 64
     constexpr int wpb = W == 64 ? 8 : 4;
     const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
-    if (ckpt) hipLaunchKernelGGL((k_linesearch<S, W, true>), dim3(grid), dim3(64 * wpb), 0, st, a);
+    if (track) {
+        // tracking cost: fused schedule only, line-search widths 8 / 16 / 32 (ilqr_ws_create maps the others onto these)
+        if constexpr (W == 8 || W == 16 || W == 32) hipLaunchKernelGGL((k_linesearch<S, W, false, true>), dim3(grid), dim3(64 * wpb), 0, st, a);
+    }
+    else if (ckpt) hipLaunchKernelGGL((k_linesearch<S, W, true>), dim3(grid), dim3(64 * wpb), 0, st, a);
     else hipLaunchKernelGGL((k_linesearch<S, W, false>), dim3(grid), dim3(64 * wpb), 0, st, a);
 }
 
@@ -276,6 +282,8 @@ size_t field_elems(const ilqr_ws* ws, int field, int* is_int, long long* tc_out,
         case ILQR_F_TRACE: tc = (long long)ws->d.n_iterations * 6; *dptr = ws->trace; break;
         case ILQR_F_STATES_OUT: tc = (long long)ws->state_rows * n; *dptr = ws->XO; break;
         case ILQR_F_INPUTS_OUT: tc = N * m; *dptr = ws->UO; break;
+        case ILQR_F_TARGET_STATES: tc = (long long)ws->state_rows * n; *dptr = ws->XD; break;
+        case ILQR_F_TARGET_INPUTS: tc = N * m; *dptr = ws->UD; break;
         default: return 0;
     }
     *tc_out = tc;
@@ -497,7 +505,8 @@ int ws_rollout(ilqr_ws* ws, int sub = -1)
 int ws_backward(ilqr_ws* ws, int it, int sub = -1)
 {
     return run_pass(ws, KID_BACKWARD, it, "k_backward", [&](auto S, const KArgs& a, hipStream_t st) {
-        hipLaunchKernelGGL(k_backward<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+        if (ws->d.tracking) hipLaunchKernelGGL((k_backward<decltype(S), true>), dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(k_backward<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
     }, sub);
 }
 // One launch per round of W trials.  Round 0 runs every active problem in place; a problem none of whose W trials passed
@@ -524,14 +533,14 @@ int ws_linesearch(ilqr_ws* ws, int sub = -1)
             a.ls_j0 = j0;
             a.ls_last = r + 1 == rounds;
             a.ls_count = cnt;
-            const bool ck = ws->split != 0;
+            const bool ck = ws->split != 0, tr = ws->d.tracking != 0;
             switch (Wr) {
                 case 1: launch_ls<T, 1>(s, a, ck); break;
                 case 2: launch_ls<T, 2>(s, a, ck); break;
                 case 4: launch_ls<T, 4>(s, a, ck); break;
-                case 8: launch_ls<T, 8>(s, a, ck); break;
-                case 16: launch_ls<T, 16>(s, a, ck); break;
-                case 32: launch_ls<T, 32>(s, a, ck); break;
+                case 8: launch_ls<T, 8>(s, a, ck, tr); break;
+                case 16: launch_ls<T, 16>(s, a, ck, tr); break;
+                case 32: launch_ls<T, 32>(s, a, ck, tr); break;
                 default: launch_ls<T, 64>(s, a, ck); break;
             }
             if (!a.ls_last) hipLaunchKernelGGL(k_ls_compact, dim3((unsigned)((a.n_tiles * TILE + 1023) / 1024)), dim3(1024), 0, s, a);
@@ -590,6 +599,9 @@ int validate_desc(const ilqr_desc* d)
     if (d->riccati < 0 || d->riccati > 3) return fail(-1, "riccati must be 0 (auto), 1 (lane per problem), 2 (16-lane group) or 3 (4-lane quad)");
     if (d->pipeline < 0 || d->pipeline > 2) return fail(-1, "pipeline must be 0 (auto), 1 (fused) or 2 (split)");
     if (d->device_wrap < 0 || d->device_wrap > 1) return fail(-1, "device_wrap must be 0 or 1");
+    if (d->tracking < 0 || d->tracking > 1) return fail(-1, "tracking must be 0 or 1");
+    if (d->tracking && (d->pipeline == 2 || d->riccati > 1 || d->n_streams > 1))
+        return fail(-1, "the tracking cost runs on the fused schedule (pipeline 0/1, riccati 0/1, one stream)");
     if (!(d->learning_speed > 0.0 && d->learning_speed < 1.0)) return fail(-1, "learning_speed must be in (0,1)");
     if (!(d->low_learning_rate > 0.0 && d->low_learning_rate < 1.0)) return fail(-1, "low_learning_rate must be in (0,1)");
     if (!(d->search_floor > 0.0 && d->search_floor < 1.0)) return fail(-1, "search_floor must be in (0,1) (the reference's literal is 0.05)");
@@ -664,6 +676,7 @@ void ilqr_desc_default(ilqr_desc* d)
     d->search_floor = 0.05;
     d->n_devices = 0;
     d->device_wrap = 0;
+    d->tracking = 0;
 }
 
 int ilqr_abi_version(void) { return ILQR_ABI_VERSION; }
@@ -776,6 +789,7 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
         W = 16;
         while (W < 32 && ws->Bpad * (long long)(W * 2) / TILE <= 4096) W *= 2;
     }
+    if (d->tracking) W = W < 8 ? 8 : (W > 32 ? 32 : W);      // the tracking line search is compiled for 8, 16 and 32 trials per round
     ws->W = W;
     // Round widths.  Fixed (every round W trials) when the caller chose W or the batch is small enough that a round is a
     // latency-bound pass over the horizon (fewer, wider rounds win).  For batches that fill the chip several times over
@@ -784,7 +798,7 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
     // ones (acrobot: 22) no more than before: 131 072 pendulums 1.24 -> 1.9 M solves/s.  Results do not depend on it.
     ws->ls_rounds_n = 0;
     {
-        const bool widen = d->n_alpha_parallel == 0 && ws->Bpad >= 32768;
+        const bool widen = d->n_alpha_parallel == 0 && ws->Bpad >= 32768 && !d->tracking;
         const int first = ws->n > 4 ? 8 : 4;
         int covered = 0;
         while (covered < n_trials) {
@@ -811,10 +825,10 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
     // idle, so the parallel parts (accept re-roll, Jacobians) are split off; large batches fill the chip either way and
     // keep the fused kernels (no LIN / checkpoint traffic).
     ws->split = d->pipeline == 2 || (d->pipeline == 0 && ws->tiles < 1024);
-    if (d->n_iterations == 0) ws->split = 0;
+    if (d->n_iterations == 0 || d->tracking) ws->split = 0;
     // Riccati recursion: one lane per problem while V_xx fits its registers (n <= 4), a lane group with LDS hand-offs
     // beyond (always through the split schedule, which provides LIN); riccati = 1 / 2 forces lane / group
-    ws->grp = d->riccati == 2 || (d->riccati == 0 && ws->n > 4);
+    ws->grp = !d->tracking && (d->riccati == 2 || (d->riccati == 0 && ws->n > 4));
     if (ws->grp) ws->split = 1;
     // four lanes per problem (k_riccati_quad): a shorter instruction chain per step on a chip the lane kernel leaves
     // idle.  Measured on the acrobot (N = 3000): 4096 problems 1.87 -> 1.44 ms, 8192 1.88 -> 1.62, 12 288 1.93 -> 2.15
@@ -847,6 +861,7 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
         {(void**)&ws->CKPT, ws->split ? Bp * (size_t)ws->n_seg * n * TILE * 8 : 0},
         {(void**)&ws->LIN, ws->split ? Bp * N * (size_t)ws->n_lin * 8 : 0},
         {(void**)&ws->VST, ws->overlap ? Bp * (n * n + n + 4) * 8 : 0},
+        {(void**)&ws->XD, d->tracking ? Bp * (N + 1) * n * 8 : 0}, {(void**)&ws->UD, d->tracking ? Bp * N * m * 8 : 0},
     };
     ws->hbm_bytes = 0;
     for (auto& al : allocs) {
@@ -928,7 +943,7 @@ int ilqr_ws_destroy(ilqr_ws* ws)
     if (ws->pipe_stream) { (void)hipStreamSynchronize(ws->pipe_stream); (void)hipStreamDestroy(ws->pipe_stream); }
     for (int c = 0; c < OVERLAP_CHUNKS; ++c) if (ws->pipe_ev[c]) (void)hipEventDestroy(ws->pipe_ev[c]);
     if (ws->pipe_done) (void)hipEventDestroy(ws->pipe_done);
-    void* ptrs[] = {ws->VST, ws->XB, ws->CKPT, ws->LIN, ws->X, ws->U, ws->G, ws->KFB, ws->KFF, ws->XO, ws->UO, ws->INIT, ws->TARGET, ws->PARAMS, ws->WTS, ws->alphas,
+    void* ptrs[] = {ws->XD, ws->UD, ws->VST, ws->XB, ws->CKPT, ws->LIN, ws->X, ws->U, ws->G, ws->KFB, ws->KFF, ws->XO, ws->UO, ws->INIT, ws->TARGET, ws->PARAMS, ws->WTS, ws->alphas,
                     ws->alpha_pp, ws->cost, ws->new_cost, ws->dJ, ws->trace, ws->active, ws->iters, ws->status, ws->acc_j,
                     ws->ls_rounds, ws->accepts, ws->ls_list, ws->ls_count, ws->staging};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1013,7 +1028,8 @@ int ilqr_ws_rollout(ilqr_ws* ws) { return ws_rollout(ws); }
 int ilqr_ws_cost(ilqr_ws* ws)
 {
     return run_pass(ws, KID_COST, 0, "k_cost", [&](auto S, const KArgs& a, hipStream_t st) {
-        hipLaunchKernelGGL(k_cost<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+        if (ws->d.tracking) hipLaunchKernelGGL((k_cost<decltype(S), true>), dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(k_cost<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
     });
 }
 int ilqr_ws_backward(ilqr_ws* ws, int32_t iteration)
@@ -1041,8 +1057,57 @@ int ilqr_ws_forward(ilqr_ws* ws, int32_t with_cost)
     return run_pass(ws, KID_FORWARD, 0, "k_forward", [&](auto S, const KArgs& a0, hipStream_t st) {
         KArgs a = a0;
         a.XO = ws->XO; a.UO = ws->UO;
-        hipLaunchKernelGGL((k_forward<decltype(S), false>), dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+        if (ws->d.tracking) hipLaunchKernelGGL((k_forward<decltype(S), false, true>), dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_forward<decltype(S), false>), dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
     });
+}
+
+// ---- receding-horizon tracking solve: matlab/smooth-ilqr/ilqr_mpc.m ----
+int ilqr_ws_mpc_shift(ilqr_ws* ws, int32_t span)
+{
+    if (!ws) return fail(-1, "null workspace");
+    if (!ws->d.tracking) return fail(-1, "ilqr_ws_mpc_shift needs a workspace created with tracking = 1");
+    if (span < 0) return fail(-1, "span must be >= 0");
+    if (span == 0) return 0;
+    const int n = ws->n, m = ws->m;
+    return run_pass(ws, KID_FORWARD, 0, "k_mpc_shift", [&](auto, const KArgs& a, hipStream_t st) {
+        hipLaunchKernelGGL(k_mpc_shift, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a, n, m, (int)span);
+    }, -1, false);
+}
+
+int ilqr_ws_mpc_solve(ilqr_ws* ws, int32_t first_call)
+{
+    if (!ws) return fail(-1, "null workspace");
+    if (!ws->d.tracking) return fail(-1, "ilqr_ws_mpc_solve needs a workspace created with tracking = 1");
+    int rc;
+    if ((rc = ilqr_ws_reset(ws))) return rc;
+    if (first_call) {
+        // ilqr_mpc.m:68-78: the gain schedule of the first call is one backward pass along the reference window itself
+        // (STATES / INPUTS hold it); no stop test, and it does not count as an iteration
+        const double low_red = ws->d.low_expected_reduction;
+        ws->d.low_expected_reduction = 0.0;
+        rc = ws_backward(ws, ws->d.n_iterations);      // trace row out of range: nothing recorded
+        ws->d.low_expected_reduction = low_red;
+        if (rc) return rc;
+        if ((rc = fill_i32(ws, ws->iters, 0))) return rc;
+        // (a problem whose Q_uu was exactly singular there stays stopped with status 3, as the reference would have raised)
+    }
+    // :127-134  closed-loop rollout from the current state around the warm start with learning rate 0, in place; its cost
+    // is the current cost
+    if ((rc = set_device(ws))) return rc;
+    HIPCHK(hipMemsetAsync(ws->alpha_pp, 0, (size_t)ws->Bpad * 8, ws->stream));
+    rc = run_pass(ws, KID_FORWARD, 0, "k_forward<tracking>", [&](auto S, const KArgs& a0, hipStream_t st) {
+        KArgs a = a0;
+        a.XO = ws->X; a.UO = ws->U; a.fwd_to_cost = 1;
+        hipLaunchKernelGGL((k_forward<decltype(S), false, true>), dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+    });
+    if (rc) return rc;
+    for (int it = 0; it < ws->d.n_iterations; ++it) {                // :142-184
+        if ((rc = ws_backward(ws, it))) return rc;
+        if ((rc = ws_linesearch(ws))) return rc;
+        if ((rc = ws_accept(ws, it))) return rc;
+    }
+    return 0;
 }
 int ilqr_ws_ltvlqr(ilqr_ws* ws)
 {

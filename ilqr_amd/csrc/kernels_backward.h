@@ -41,7 +41,9 @@ __device__ __forceinline__ void backward_epilogue(const KArgs& a, long long tile
 // ------------------------------------------------------------------------------------------------
 // k_backward: ilqr.py:64-135.  One lane per problem; V_x, V_xx and the step's Q_* stay in VGPRs.
 // ------------------------------------------------------------------------------------------------
-template <class S>
+// TRACK: the tracking cost of matlab/smooth-ilqr/ilqr_mpc.m:236-308 -- per-step targets x_des, u_des (XD, UD), l_x = Q_k (x - x_des),
+// l_u = R_k (u - u_des), terminal target = the last row of x_des (:247).
+template <class S, bool TRACK = false>
 __global__ void __launch_bounds__(64) k_backward(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
@@ -52,7 +54,9 @@ __global__ void __launch_bounds__(64) k_backward(const KArgs a)
     if (__ballot(act) == 0ull) return;   // whole tile finished
     double p[np], target[n], Qk[n * n], Rk[m * m], Vx[n], Vxx[n * n];
     load_col<np>(a.PARAMS + (size_t)tile * np * TILE + lane, p);
-    load_col<n>(a.TARGET + (size_t)tile * n * TILE + lane, target);
+    const double* XDp = TRACK ? a.XD + (size_t)tile * a.state_rows * n * TILE + lane : nullptr;
+    const double* UDp = TRACK ? a.UD + (size_t)tile * a.N * m * TILE + lane : nullptr;
+    load_col<n>(TRACK ? XDp + (size_t)a.N * n * TILE : a.TARGET + (size_t)tile * n * TILE + lane, target);
     load_uniform<n * n>(a.WTS, Qk);
     load_uniform<m * m>(a.WTS + n * n, Rk);
     load_uniform<n * n>(a.WTS + n * n + m * m, Vxx);                                   // :67  V_xx = Q_T
@@ -74,7 +78,38 @@ __global__ void __launch_bounds__(64) k_backward(const KArgs a)
         double A[n * n], Bm[n * m], k[m], K[m * n], g, h;
         S::A(x, u, a.dt, p, A);                                                        // :96
         S::B(x, u, a.dt, p, Bm);                                                       // :97
-        ok = Riccati<S>::step(A, Bm, u, Qk, Rk, a.quu_reg, Vx, Vxx, k, K, g, h) && ok;
+        if constexpr (TRACK) {
+            double xd[n], ud[m], ex[n], du[m], lx[n];
+            load_col<n>(XDp + (size_t)t * n * TILE, xd);
+            load_col<m>(UDp + (size_t)t * m * TILE, ud);
+#pragma unroll
+            for (int i = 0; i < n; ++i) ex[i] = x[i] - xd[i];
+#pragma unroll
+            for (int j = 0; j < m; ++j) du[j] = u[j] - ud[j];
+            if constexpr (n > 4) {
+                // rolled, Q_k read from memory: with Q_k's 144 entries unrolled into this kernel's registers next to
+                // V_xx, A and Q_xx, hipcc 7.2 -O3 emits a kernel that computes wrong gains (correct at -O1 and without
+                // this product; tools/dbg notes in DESIGN.md).  ex and lx are indexed dynamically, i.e. live in scratch.
+#pragma nounroll
+                for (int i = 0; i < n; ++i) {
+                    double s = 0.0;
+#pragma nounroll
+                    for (int c = 0; c < n; ++c) s = __builtin_fma(a.WTS[i * n + c], ex[c], s);
+                    lx[i] = s;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < n; ++i) {                                          // ilqr_mpc.m:260  l_x = Q_k (x - x_des)
+                    double s = 0.0;
+#pragma unroll
+                    for (int c = 0; c < n; ++c) s = __builtin_fma(Qk[i * n + c], ex[c], s);
+                    lx[i] = s;
+                }
+            }
+            ok = Riccati<S>::template step<true>(A, Bm, du, Qk, Rk, a.quu_reg, Vx, Vxx, k, K, g, h, lx) && ok;
+        } else {
+            ok = Riccati<S>::step(A, Bm, u, Qk, Rk, a.quu_reg, Vx, Vxx, k, K, g, h) && ok;
+        }
         if (act) {
             store_col<m>(kp + (size_t)t * m * TILE, k);                                // :111
             store_col<m * n>(Kp + (size_t)t * (m * n) * TILE, K);                      // :112

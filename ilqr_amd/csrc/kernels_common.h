@@ -74,6 +74,10 @@ struct KArgs {
     double* X;             // [tile][state_rows][n][64]
     double* U;             // [tile][N][m][64]
     const double* G;       // [tile][N][m][64] initial guess (read by k_rollout only)
+    // tracking cost (ilqr_desc.tracking, matlab/smooth-ilqr/ilqr_mpc.m): per-step targets of the horizon window
+    const double* XD;      // [tile][N+1][n][64] x_des: rows 0..N-1 stage targets, row N the terminal target (ilqr_mpc.m:203,213,247,255)
+    const double* UD;      // [tile][N][m][64]   u_des (ilqr_mpc.m:204,256)
+    int fwd_to_cost;       // k_forward<false>: the cost of the new trajectory also becomes the current cost (ilqr_mpc.m:127-134)
     double* KFB;           // [tile][N][m*n][64]
     double* KFF;           // [tile][N][m][64]
     double* XB;            // split pipeline: [tile][segment][n][64] reference-state row at every segment boundary, saved before the in-place accept
@@ -333,10 +337,13 @@ struct Riccati {
 
     // One step of ilqr.backwards_pass (ilqr.py:84-125).  A, Bm: Jacobians at (x_t,u_t).  Updates Vx, Vxx in place,
     // returns k, K and the step's (grad, hess) expected-reduction terms.
+    // TRACK (tracking cost, matlab/smooth-ilqr/ilqr_mpc.m:260-272): l_x = Q_k (x - x_des) is handed in as `lx` and added to
+    // Q_x; `u` is then u - u_des, so that l_u = R_k (u - u_des) comes out of the same product (:263).
+    template <bool TRACK = false>
     static __device__ __forceinline__ bool step(const double (&A)[n * n], const double (&Bm)[n * m], const double (&u)[m],
                                                 const double (&Qk)[n * n], const double (&Rk)[m * m], double quu_reg,
                                                 double (&Vx)[n], double (&Vxx)[n * n], double (&k)[m], double (&K)[m * n],
-                                                double& g_out, double& h_out)
+                                                double& g_out, double& h_out, const double (&lx)[n])
     {
         double Qx[n], Qu[m], BtV[m * n], Qux[m * n], Quu[m * m], Qxx[n * n], Quu_inv[m * m];
         // :99  Q_x = A.T @ V_x   (l_x = Q_k @ 0 = 0)
@@ -345,7 +352,7 @@ struct Riccati {
             double s = 0.0; bool first = true;
 #pragma unroll
             for (int r = 0; r < n; ++r) acc_term(s, first, S::a_kind(r * n + i), A[r * n + i], Vx[r]);
-            Qx[i] = s;
+            Qx[i] = TRACK ? lx[i] + s : s;                                             // ilqr_mpc.m:271
         }
         // :93,:100  Q_u = R_k @ u + B.T @ V_x
 #pragma unroll
@@ -469,6 +476,15 @@ struct Riccati {
         }
         return ok;
     }
+
+    static __device__ __forceinline__ bool step(const double (&A)[n * n], const double (&Bm)[n * m], const double (&u)[m],
+                                                const double (&Qk)[n * n], const double (&Rk)[m * m], double quu_reg,
+                                                double (&Vx)[n], double (&Vxx)[n * n], double (&k)[m], double (&K)[m * n],
+                                                double& g_out, double& h_out)
+    {
+        const double none[n] = {};
+        return step<false>(A, Bm, u, Qk, Rk, quu_reg, Vx, Vxx, k, K, g_out, h_out, none);
+    }
 };
 
 // stage cost of compute_cost (ilqr.py:56): (u^T R) u
@@ -484,6 +500,26 @@ __device__ __forceinline__ double input_cost(const double (&u)[m], const double 
         c = __builtin_fma(s, u[j], c);
     }
     return c;
+}
+// tracking stage cost (matlab/smooth-ilqr/ilqr_mpc.m:207-209): (u_des - u)' R (u_des - u) + (x_des - x)' Q_k (x_des - x)
+template <int n, int m>
+__device__ __forceinline__ double tracking_stage_cost(const double (&x)[n], const double (&u)[m], const double (&xd)[n],
+                                                      const double (&ud)[m], const double (&Qk)[n * n], const double (&Rk)[m * m])
+{
+    double du[m], dx[n];
+#pragma unroll
+    for (int j = 0; j < m; ++j) du[j] = ud[j] - u[j];
+#pragma unroll
+    for (int i = 0; i < n; ++i) dx[i] = xd[i] - x[i];
+    double cx = 0.0;
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) s = __builtin_fma(dx[i], Qk[i * n + j], s);
+        cx = __builtin_fma(s, dx[j], cx);
+    }
+    return input_cost<m>(du, Rk) + cx;
 }
 // terminal cost (ilqr.py:59-60): d = target - x_N, (d^T Q_T) d
 template <int n>

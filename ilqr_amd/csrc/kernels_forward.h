@@ -80,24 +80,43 @@ __global__ void __launch_bounds__(64) k_rollout(const KArgs a)
 }
 
 // k_cost: compute_cost (ilqr.py:49-62) of the stored trajectory.
-template <class S>
+// TRACK: the tracking cost of matlab/smooth-ilqr/ilqr_mpc.m:193-216 (per-step targets XD, UD; stage cost over rows 0..N-1
+// of the states, terminal cost against the last row of XD).
+template <class S, bool TRACK = false>
 __global__ void __launch_bounds__(64) k_cost(const KArgs a)
 {
     constexpr int n = S::n, m = S::m;
     const long long tile = a.tile0 + blockIdx.x;
     const int lane = threadIdx.x;
     double x[n], target[n], Rk[m * m], QT[n * n];
-    load_col<n>(a.TARGET + (size_t)tile * n * TILE + lane, target);
     load_uniform<m * m>(a.WTS + n * n, Rk);
     load_uniform<n * n>(a.WTS + n * n + m * m, QT);
     const double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+    const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
     double cost = 0.0;
-    for (int t = 0; t < a.N; ++t) {
-        double u[m];
-        load_col<m>(Up + (size_t)t * m * TILE, u);
-        cost = cost + input_cost<m>(u, Rk);
+    if constexpr (TRACK) {
+        double Qk[n * n];
+        load_uniform<n * n>(a.WTS, Qk);
+        const double* XDp = a.XD + (size_t)tile * a.state_rows * n * TILE + lane;
+        const double* UDp = a.UD + (size_t)tile * a.N * m * TILE + lane;
+        for (int t = 0; t < a.N; ++t) {
+            double u[m], xd[n], ud[m];
+            load_col<m>(Up + (size_t)t * m * TILE, u);
+            load_col<n>(Xp + (size_t)t * n * TILE, x);
+            load_col<n>(XDp + (size_t)t * n * TILE, xd);
+            load_col<m>(UDp + (size_t)t * m * TILE, ud);
+            cost = cost + tracking_stage_cost<n, m>(x, u, xd, ud, Qk, Rk);
+        }
+        load_col<n>(XDp + (size_t)a.N * n * TILE, target);
+    } else {
+        load_col<n>(a.TARGET + (size_t)tile * n * TILE + lane, target);
+        for (int t = 0; t < a.N; ++t) {
+            double u[m];
+            load_col<m>(Up + (size_t)t * m * TILE, u);
+            cost = cost + input_cost<m>(u, Rk);
+        }
     }
-    load_col<n>(a.X + ((size_t)tile * a.state_rows + a.N) * n * TILE + lane, x);
+    load_col<n>(Xp + (size_t)a.N * n * TILE, x);
     cost = cost + terminal_cost<n>(x, target, QT);
     a.cost[tile * TILE + lane] = cost;
 }
@@ -122,14 +141,17 @@ __global__ void __launch_bounds__(64) k_cost(const KArgs a)
 #ifndef CLOSED_LOOP_SCHED_BARRIER
 #define CLOSED_LOOP_SCHED_BARRIER 1
 #endif
-template <class S, bool STORE, bool CKPT, bool LINOUT = false>
+template <class S, bool STORE, bool CKPT, bool LINOUT = false, bool TRACK = false>
 __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double* Xp, const double* Up, const double* Kp,
                                                     const double* kp, double* XOp, double* UOp, double* ckp,
                                                     double (&x)[S::n], const double (&p)[S::np],
                                                     const double (&Rk)[S::m * S::m], const double alpha, const int t0,
                                                     const int t1, const double* Xfirst = nullptr, double* Lp = nullptr,
-                                                    const double kill_at = __builtin_inf())
+                                                    const double kill_at = __builtin_inf(), const double* XDp = nullptr,
+                                                    const double* UDp = nullptr)
 {
+    // TRACK: the stage cost is the tracking cost of ilqr_mpc.m:207-209 against the per-step targets XDp, UDp (read one
+    // step ahead; these rollouts keep the plain one-step prefetch of the records, the ring is for the headline path)
     // kill_at (line-search trials only, STORE = false): once the running cost exceeds it the trial is known to fail the
     // Armijo test (k_linesearch sets it where that is provable) and the lane's remaining steps are don't-cares.
     // Xfirst: where the reference-state row of step t0 is kept when X itself is being overwritten by a neighbour
@@ -140,7 +162,13 @@ __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double
     // the trajectory row is one step ahead and the gains are left to the scheduler.  A slot is refilled as soon as
     // its step's input is formed, i.e. row t+D of X is read before the STORE of row t+1 (in-place accept, D >= 1).
     constexpr bool PREFETCH = (n + 2 * m + m * n) <= 16;
-    constexpr int D = PREFETCH ? (LINOUT ? ACCEPT_PREFETCH : CLOSED_LOOP_PREFETCH) : 1;   // the accept streams: deeper
+    constexpr int D = PREFETCH ? (LINOUT || TRACK ? ACCEPT_PREFETCH : CLOSED_LOOP_PREFETCH) : 1;   // the accept streams: deeper
+    double Qk[TRACK ? n * n : 1], xdn[TRACK ? n : 1], udn[TRACK ? m : 1];
+    if constexpr (TRACK) {
+        load_uniform<n * n>(a.WTS, Qk);
+        load_col<n>(XDp + (size_t)t0 * n * TILE, xdn);
+        load_col<m>(UDp + (size_t)t0 * m * TILE, udn);
+    }
     double cost = 0.0;
     double xb[D][n], ub[D][m], K[D][m * n], kf[D][m];
 #pragma unroll
@@ -202,7 +230,19 @@ __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double
                 if constexpr (PREFETCH) { load_col<m * n>(Kp + (size_t)tl * (m * n) * TILE, K[d]); load_col<m>(kp + (size_t)tl * m * TILE, kf[d]); }
             }
         }
-        cost = cost + input_cost<m>(u, Rk);
+        if constexpr (TRACK) {
+            double xd[n], ud[m];
+#pragma unroll
+            for (int i = 0; i < n; ++i) xd[i] = xdn[i];
+#pragma unroll
+            for (int j = 0; j < m; ++j) ud[j] = udn[j];
+            const int tn = t + 1 < t1 ? t + 1 : t1 - 1;
+            load_col<n>(XDp + (size_t)tn * n * TILE, xdn);
+            load_col<m>(UDp + (size_t)tn * m * TILE, udn);
+            cost = cost + tracking_stage_cost<n, m>(x, u, xd, ud, Qk, Rk);         // ilqr_mpc.m:207-210
+        } else {
+            cost = cost + input_cost<m>(u, Rk);
+        }
         if constexpr (S::n_ang > 0) {
             S::f_sc(x, u, a.dt, p, trig.sc, xn);                                   // :151
             const bool reseed = t + 1 == next_seed;
@@ -231,14 +271,16 @@ __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double
     return cost;
 }
 
-template <class S, bool STORE, bool CKPT = false>
+template <class S, bool STORE, bool CKPT = false, bool TRACK = false>
 __device__ __forceinline__ double closed_loop(const KArgs& a, const double* Xp, const double* Up, const double* Kp,
                                               const double* kp, double* XOp, double* UOp, double (&x)[S::n],
                                               const double (&p)[S::np], const double (&target)[S::n],
                                               const double (&Rk)[S::m * S::m], const double (&QT)[S::n * S::n],
-                                              const double alpha, double* ckp = nullptr, const double kill_at = __builtin_inf())
+                                              const double alpha, double* ckp = nullptr, const double kill_at = __builtin_inf(),
+                                              const double* XDp = nullptr, const double* UDp = nullptr)
 {
-    double cost = closed_loop_range<S, STORE, CKPT>(a, Xp, Up, Kp, kp, XOp, UOp, ckp, x, p, Rk, alpha, 0, a.N, nullptr, nullptr, kill_at);
+    double cost = closed_loop_range<S, STORE, CKPT, false, TRACK>(a, Xp, Up, Kp, kp, XOp, UOp, ckp, x, p, Rk, alpha, 0, a.N, nullptr,
+                                                                  nullptr, kill_at, XDp, UDp);
     cost = cost + terminal_cost<S::n>(x, target, QT);
     return cost;
 }
@@ -353,7 +395,7 @@ constexpr int ls_waves_per_simd()
 {
     return S::n > 4 ? 1 : (S::id == ILQR_DYN_ACROBOT_ID ? 2 : LS_WAVES_SMALL);   // (4 for cartpole spills 14 VGPRs and gains nothing)
 }
-template <class S, int W, bool CKPT>
+template <class S, int W, bool CKPT, bool TRACK = false>
 __global__ void __launch_bounds__(W == 64 ? 512 : 256, ls_waves_per_simd<S>()) k_linesearch(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
@@ -383,7 +425,9 @@ __global__ void __launch_bounds__(W == 64 ? 512 : 256, ls_waves_per_simd<S>()) k
     double x0[n], p[np], target[n], Rk[m * m], QT[n * n];
     load_col<n>(a.INIT + (size_t)tile * n * TILE + pl, x0);
     load_col<np>(a.PARAMS + (size_t)tile * np * TILE + pl, p);
-    load_col<n>(a.TARGET + (size_t)tile * n * TILE + pl, target);
+    const double* XDp = TRACK ? a.XD + (size_t)tile * a.state_rows * n * TILE + pl : nullptr;
+    const double* UDp = TRACK ? a.UD + (size_t)tile * a.N * m * TILE + pl : nullptr;
+    load_col<n>(TRACK ? XDp + (size_t)a.N * n * TILE : a.TARGET + (size_t)tile * n * TILE + pl, target);   // ilqr_mpc.m:213
     load_uniform<m * m>(a.WTS + n * n, Rk);
     load_uniform<n * n>(a.WTS + n * n + m * m, QT);
     const double cur_cost = a.cost[b];
@@ -396,7 +440,7 @@ __global__ void __launch_bounds__(W == 64 ? 512 : 256, ls_waves_per_simd<S>()) k
     const bool valid = act && j < a.n_trials;
     double c = __builtin_nan("");
     bool okj = false;
-    if constexpr (Staged<S, W>::use) {
+    if constexpr (Staged<S, W>::use && !TRACK) {
         // whole wave together (the record loads are shared); lanes without a trial compute on and are ignored
         __shared__ double sh[(W == 64 ? 8 : 4) * Staged<S, W>::WAVE_DOUBLES];
         double* sw = sh + (threadIdx.x >> 6) * Staged<S, W>::WAVE_DOUBLES;
@@ -424,9 +468,9 @@ __global__ void __launch_bounds__(W == 64 ? 512 : 256, ls_waves_per_simd<S>()) k
         // never decreases along the rollout (every stage term is a rounded R_jj u_j^2 >= 0), so once it has passed the
         // current cost the outcome is known -- exactly, in floating point -- and the rest of the lane's rollout is a
         // don't-care (diverging trials stop forcing the full trig evaluation on their wave; see TrigCarry::advance).
-        const bool provable = a.cost_monotone != 0 && expected > 0.0 && a.armijo_thr >= 0.0;
-        c = closed_loop<S, false, CKPT>(a, Xp, Up, Kp, kp, nullptr, nullptr, x, p, target, Rk, QT, alpha, ckp,
-                                        provable ? cur_cost : __builtin_inf());
+        const bool provable = !TRACK && a.cost_monotone != 0 && expected > 0.0 && a.armijo_thr >= 0.0;
+        c = closed_loop<S, false, CKPT, TRACK>(a, Xp, Up, Kp, kp, nullptr, nullptr, x, p, target, Rk, QT, alpha, ckp,
+                                               provable ? cur_cost : __builtin_inf(), XDp, UDp);
         const double cost_difference = cur_cost - c;                               // :191
         okj = (cost_difference / expected) > a.armijo_thr;                         // :193 (NaN -> false)
     }
@@ -481,7 +525,7 @@ __global__ void __launch_bounds__(1024) k_ls_compact(const KArgs a)
 //                   in place into X/U, take new_cost as their cost; the others stop with "low learning rate".
 //   ACCEPT = false: plain forwards_pass with a per-problem alpha into XO/UO (+ its cost into new_cost).
 // ------------------------------------------------------------------------------------------------
-template <class S, bool ACCEPT>
+template <class S, bool ACCEPT, bool TRACK = false>
 __global__ void __launch_bounds__(64) k_forward(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
@@ -504,7 +548,9 @@ __global__ void __launch_bounds__(64) k_forward(const KArgs a)
     double x[n], p[np], target[n], Rk[m * m], QT[n * n];
     load_col<n>(a.INIT + (size_t)tile * n * TILE + lane, x);
     load_col<np>(a.PARAMS + (size_t)tile * np * TILE + lane, p);
-    load_col<n>(a.TARGET + (size_t)tile * n * TILE + lane, target);
+    const double* XDp = TRACK ? a.XD + (size_t)tile * a.state_rows * n * TILE + lane : nullptr;
+    const double* UDp = TRACK ? a.UD + (size_t)tile * a.N * m * TILE + lane : nullptr;
+    load_col<n>(TRACK ? XDp + (size_t)a.N * n * TILE : a.TARGET + (size_t)tile * n * TILE + lane, target);
     load_uniform<m * m>(a.WTS + n * n, Rk);
     load_uniform<n * n>(a.WTS + n * n + m * m, QT);
     const double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
@@ -514,13 +560,13 @@ __global__ void __launch_bounds__(64) k_forward(const KArgs a)
     double* XOp = a.XO + (size_t)tile * a.state_rows * n * TILE + lane;
     double* UOp = a.UO + (size_t)tile * a.N * m * TILE + lane;
     if (run) {
-        if constexpr (!ACCEPT) {
-            double x0[n];
+        double x0[n];
 #pragma unroll
-            for (int i = 0; i < n; ++i) x0[i] = a.zero_first ? 0.0 : x[i];             // :138,:143 (row 0 stays zero)
-            store_col<n>(XOp, x0);
-        }
-        const double c = closed_loop<S, true>(a, Xp, Up, Kp, kp, XOp, UOp, x, p, target, Rk, QT, alpha);
+        for (int i = 0; i < n; ++i) x0[i] = a.zero_first ? 0.0 : x[i];                 // :138,:143 (row 0 stays zero)
+        const double c = closed_loop<S, true, false, TRACK>(a, Xp, Up, Kp, kp, XOp, UOp, x, p, target, Rk, QT, alpha, nullptr,
+                                                            __builtin_inf(), XDp, UDp);
+        // row 0 last: XO may be X itself (ilqr_ws_mpc_solve rolls out in place), whose old row 0 is step 0's reference state
+        if constexpr (!ACCEPT) store_col<n>(XOp, x0);
         if constexpr (ACCEPT) {
             const double nc = a.new_cost[b];          // cost of the winning trial as the line search saw it
             a.cost[b] = nc;                                                            // :197
@@ -532,8 +578,36 @@ __global__ void __launch_bounds__(64) k_forward(const KArgs a)
             (void)c;
         } else {
             a.new_cost[b] = c;
+            if (a.fwd_to_cost) a.cost[b] = c;                                          // ilqr_mpc.m:132
         }
     }
+}
+
+// Warm start of a receding-horizon solve (matlab/smooth-ilqr/ilqr_mpc.m:100-121): the previous solution moved `span` steps
+// along the horizon, its end padded from the new target window (XD, UD -- already holding the window of the new index), the
+// gains K moved span - 1 steps (the reference keeps rows span..end, 1-based) with the last gain repeated.  k_feedforward
+// is left alone (the next pass uses learning rate 0, :127).  One lane per problem, ascending t: row t + span is read before
+// row t is written.
+__global__ void __launch_bounds__(64) k_mpc_shift(const KArgs a, const int n, const int m, const int span)
+{
+    const long long tile = a.tile0 + blockIdx.x;
+    const int lane = threadIdx.x;
+    double* Xp = a.X + (size_t)tile * a.state_rows * n * TILE + lane;
+    double* Up = a.U + (size_t)tile * a.N * m * TILE + lane;
+    double* Kp = a.KFB + (size_t)tile * a.N * (m * n) * TILE + lane;
+    const double* XDp = a.XD + (size_t)tile * a.state_rows * n * TILE + lane;
+    const double* UDp = a.UD + (size_t)tile * a.N * m * TILE + lane;
+    for (int t = 0; t <= a.N; ++t)
+        for (int i = 0; i < n; ++i)
+            Xp[((size_t)t * n + i) * TILE] = t + span <= a.N ? Xp[((size_t)(t + span) * n + i) * TILE] : XDp[((size_t)t * n + i) * TILE];
+    for (int t = 0; t < a.N; ++t)
+        for (int j = 0; j < m; ++j)
+            Up[((size_t)t * m + j) * TILE] = t + span < a.N ? Up[((size_t)(t + span) * m + j) * TILE] : UDp[((size_t)t * m + j) * TILE];
+    if (span > 1)
+        for (int t = 0; t < a.N; ++t) {
+            const int ts = t + span - 1 < a.N ? t + span - 1 : a.N - 1;
+            for (int e = 0; e < m * n; ++e) Kp[((size_t)t * (m * n) + e) * TILE] = Kp[((size_t)ts * (m * n) + e) * TILE];
+        }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ILQR_ABI_VERSION 6
+#define ILQR_ABI_VERSION 7
 
 /* systems compiled into the library (sympy-generated __device__ dynamics, ilqr_amd/csrc/dynamics/) */
 enum { ILQR_SYS_PENDULUM = 0, ILQR_SYS_ACROBOT = 1, ILQR_SYS_CARTPOLE = 2, ILQR_SYS_QUADCOPTER = 3, ILQR_SYS_CAR = 4,
@@ -86,6 +86,11 @@ typedef struct ilqr_desc {
                                      is per device (ilqr_ws_create ignores this field). */
     int32_t device_wrap;          /* 0: a shard whose device ordinal is not visible is an error; 1: ordinals wrap modulo the
                                      visible devices (several shards per GPU: tests on a one-GPU box) */
+    int32_t tracking;             /* 1: the trajectory-tracking cost of matlab/smooth-ilqr/ilqr_mpc.m -- per-step targets
+                                     x_des (N+1 rows, the last one the terminal target) and u_des (fields TARGET_STATES /
+                                     TARGET_INPUTS) replace target_state: stage cost (u_des-u)'R_k(u_des-u) + (x_des-x)'Q_k(x_des-x)
+                                     (:207-209), l_x = Q_k (x - x_des), l_u = R_k (u - u_des) (:260-263).  Fused schedule.  With
+                                     x_des = target_state in every row, u_des = 0 and Q_k = 0 this is ilqr.py's cost, bit for bit. */
 } ilqr_desc;
 
 void ilqr_desc_default(ilqr_desc* d);
@@ -184,7 +189,9 @@ enum {  /* fields, reference layout with leading B */
     ILQR_F_STATES_OUT = 15, /* (B,N+1,n) out of ilqr_ws_forward */
     ILQR_F_INPUTS_OUT = 16, /* (B,N,m)   out of ilqr_ws_forward */
     ILQR_F_NEW_COST = 17, /* (B) double out: cost of the last forward / accepted trial */
-    ILQR_F_GUESS = 18     /* (B,N,m)      in: initial guess read by rollout()/solve(); kept, so solve() can be repeated */
+    ILQR_F_GUESS = 18,    /* (B,N,m)      in: initial guess read by rollout()/solve(); kept, so solve() can be repeated */
+    ILQR_F_TARGET_STATES = 19, /* (B,N+1,n) in: tracking cost, x_des of the horizon window (ilqr_mpc.m:203,213) */
+    ILQR_F_TARGET_INPUTS = 20  /* (B,N,m)   in: tracking cost, u_des of the horizon window (ilqr_mpc.m:204) */
 };
 
 int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out);
@@ -204,6 +211,17 @@ int ilqr_ws_accept(ilqr_ws* ws, int32_t iteration);     /* ilqr.py:194-207: re-r
 int ilqr_ws_forward(ilqr_ws* ws, int32_t with_cost);    /* ilqr.py:137-158 with ALPHA -> STATES_OUT/INPUTS_OUT (+ NEW_COST) */
 int ilqr_ws_solve(ilqr_ws* ws);            /* ilqr.py:159-211: reset, rollout, n_iterations x (backward, linesearch, accept) */
 int ilqr_ws_ltvlqr(ilqr_ws* ws);           /* ltvlqr.py:3-28 on STATES/INPUTS -> KFB */
+/* Receding-horizon tracking iLQR: matlab/smooth-ilqr/ilqr_mpc.m, solve_ilqr (:63-192), on a workspace created with
+ * tracking = 1 and zero_first_state = 0 (row 0 of the states is the current state, :314).  One call of solve_ilqr is
+ *   upload INIT (current state), TARGET_STATES / TARGET_INPUTS (the window current_idx .. current_idx + N);
+ *   first call: upload STATES / INPUTS = that window (:73-74);  later calls: ilqr_ws_mpc_shift(ws, span) (:100-121: the
+ *     previous solution moved span steps, padded from the new window; gains moved span - 1 steps, last gain repeated);
+ *   ilqr_ws_mpc_solve(ws, first_call): first call only, one backward pass along the window for the gains (:75-78); then
+ *     the closed-loop rollout with learning rate 0 (:127-134) and n_iterations x {backward, line search, accept}
+ *     (:142-184) -> STATES, INPUTS, KFF, KFB, COST as solve().  The while condition of the line search is
+ *     `learning_rate > low_learning_rate` there (:158): set search_floor = low_learning_rate (the defaults are equal). */
+int ilqr_ws_mpc_shift(ilqr_ws* ws, int32_t span);
+int ilqr_ws_mpc_solve(ilqr_ws* ws, int32_t first_call);
 int ilqr_ws_sync(ilqr_ws* ws);
 /* kernel timing with HIP events on the workspace stream.  kernel ids: 0 rollout, 1 backward, 2 linesearch, 3 accept,
  * 4 ltvlqr, 5 forward, 6 cost, 7 linearize.  In the split pipeline backward = k_riccati, accept = k_save_boundaries + k_accept_lin (which also writes A_t, B_t); linesearch = all rounds of a pass.

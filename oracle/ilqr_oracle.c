@@ -394,6 +394,223 @@ int oracle_ltvlqr_batched(int sys, int64_t B, int N, int n_rows, const double* s
     return rc;
 }
 
+/* =====================================================================================================
+ * Receding-horizon trajectory-tracking iLQR: matlab/smooth-ilqr/ilqr_mpc.m (MATLAB only: the reference has no python
+ * twin and MATLAB cannot run here, so this restatement is NOT pinned by reference outputs -- "parity unpinned"; it
+ * follows the .m file line by line, and the GPU path is tested against it and, in the degenerate case x_des = target,
+ * u_des = 0, Q_k = 0, against the pinned ilqr.py path).  Layout: states (N+1,n) with row 0 = the current state (:314),
+ * x_des (N+1,n) = target_states(current_idx : current_idx+N), u_des (N,m) = target_inputs(current_idx : current_idx+N-1).
+ * ===================================================================================================== */
+
+/* x = A \ b for the small square A (MATLAB mldivide: LU with partial pivoting); nrhs right-hand sides in the columns of
+ * the row-major b (m x nrhs).  Returns -1 on an exactly zero pivot (MATLAB warns and returns Inf/NaN). */
+static int solve_small(int m, const double* Ain, const double* b, int nrhs, double* x)
+{
+    double a[MAXM * MAXM], y[MAXM]; int piv[MAXM];
+    memcpy(a, Ain, sizeof(double) * m * m);
+    for (int c = 0; c < m; ++c) {
+        int pr = c; double best = fabs(a[c * m + c]);
+        for (int r = c + 1; r < m; ++r) if (fabs(a[r * m + c]) > best) { best = fabs(a[r * m + c]); pr = r; }
+        piv[c] = pr;
+        if (best == 0.0) return -1;
+        if (pr != c) for (int j = 0; j < m; ++j) { double t = a[c * m + j]; a[c * m + j] = a[pr * m + j]; a[pr * m + j] = t; }
+        for (int r = c + 1; r < m; ++r) {
+            a[r * m + c] = a[r * m + c] / a[c * m + c];
+            for (int j = c + 1; j < m; ++j) a[r * m + j] -= a[r * m + c] * a[c * m + j];
+        }
+    }
+    for (int col = 0; col < nrhs; ++col) {
+        for (int i = 0; i < m; ++i) y[i] = b[i * nrhs + col];
+        for (int c = 0; c < m; ++c) if (piv[c] != c) { double t = y[c]; y[c] = y[piv[c]]; y[piv[c]] = t; }
+        for (int i = 0; i < m; ++i) for (int j = 0; j < i; ++j) y[i] -= a[i * m + j] * y[j];
+        for (int i = m - 1; i >= 0; --i) {
+            for (int j = i + 1; j < m; ++j) y[i] -= a[i * m + j] * y[j];
+            y[i] = y[i] / a[i * m + i];
+        }
+        for (int i = 0; i < m; ++i) x[i * nrhs + col] = y[i];
+    }
+    return 0;
+}
+
+/* ilqr_mpc.compute_cost: ilqr_mpc.m:193-216 */
+double oracle_mpc_cost(int n, int m, int N, const double* states, const double* inputs, const double* x_des, const double* u_des,
+                       const double* Qk, const double* Rk, const double* QT)
+{
+    double total = 0.0;
+    for (int t = 0; t < N; ++t) {                                              /* :196 */
+        double xd[MAXN], ud[MAXM], tmp[MAXN];
+        for (int i = 0; i < n; ++i) xd[i] = x_des[t * n + i] - states[t * n + i];   /* :207 */
+        for (int j = 0; j < m; ++j) ud[j] = u_des[t * m + j] - inputs[t * m + j];   /* :208 */
+        double cu = 0.0, cx = 0.0;                                             /* :209  (u'R)u + (x'Q)x */
+        for (int j = 0; j < m; ++j) { double s = 0.0; for (int i = 0; i < m; ++i) s += ud[i] * Rk[i * m + j]; tmp[j] = s; }
+        for (int j = 0; j < m; ++j) cu += tmp[j] * ud[j];
+        for (int j = 0; j < n; ++j) { double s = 0.0; for (int i = 0; i < n; ++i) s += xd[i] * Qk[i * n + j]; tmp[j] = s; }
+        for (int j = 0; j < n; ++j) cx += tmp[j] * xd[j];
+        total = total + (cu + cx);                                             /* :210 */
+    }
+    double d[MAXN], dQ[MAXN], tc = 0.0;
+    for (int i = 0; i < n; ++i) d[i] = x_des[N * n + i] - states[N * n + i];    /* :213 */
+    for (int j = 0; j < n; ++j) { double s = 0.0; for (int i = 0; i < n; ++i) s += d[i] * QT[i * n + j]; dQ[j] = s; }
+    for (int j = 0; j < n; ++j) tc += dQ[j] * d[j];
+    return total + tc;                                                         /* :215 */
+}
+
+/* ilqr_mpc.backwards_pass: ilqr_mpc.m:236-308.  Returns -(t+1) on an exactly singular Q_uu. */
+int oracle_mpc_backward(int sys, int N, const double* states, const double* inputs, const double* x_des, const double* u_des,
+                        const double* Qk, const double* Rk, const double* QT, double dt, const double* p, double* k_trj,
+                        double* K_trj, double* dJ)
+{
+    const oracle_system* S = &SYSTEMS[sys];
+    const int n = S->n, m = S->m;
+    double Vxx[MAXN * MAXN], Vx[MAXN], ed[MAXN];
+    for (int i = 0; i < n; ++i) ed[i] = states[N * n + i] - x_des[N * n + i];  /* :247 */
+    mm(n, n, 1, QT, ed, Vx);
+    memcpy(Vxx, QT, sizeof(double) * n * n);                                   /* :248 */
+    double ecr = 0.0, ecr_g = 0.0, ecr_h = 0.0;
+    for (int t = N - 1; t >= 0; --t) {                                         /* :250 */
+        const double* x = states + t * n;
+        const double* u = inputs + t * m;
+        double A[MAXN * MAXN], B[MAXN * MAXM], ex[MAXN], eu[MAXM], lx[MAXN], lu[MAXM];
+        double Qx[MAXN], Qu[MAXM], BtV[MAXM * MAXN], AtV[MAXN * MAXN], Qux[MAXM * MAXN], Quu[MAXM * MAXM], Qxx[MAXN * MAXN];
+        double nQuu[MAXM * MAXM], k[MAXM], K[MAXM * MAXN];
+        for (int i = 0; i < n; ++i) ex[i] = x[i] - x_des[t * n + i];
+        for (int j = 0; j < m; ++j) eu[j] = u[j] - u_des[t * m + j];
+        mm(n, n, 1, Qk, ex, lx);                                               /* :260 */
+        mm(m, m, 1, Rk, eu, lu);                                               /* :263 */
+        S->A(x, u, dt, p, A);                                                  /* :267 */
+        S->B(x, u, dt, p, B);                                                  /* :268 */
+        mtm(n, n, 1, A, Vx, Qx);
+        for (int i = 0; i < n; ++i) Qx[i] = lx[i] + Qx[i];                     /* :271 */
+        mtm(n, m, 1, B, Vx, Qu);
+        for (int j = 0; j < m; ++j) Qu[j] = lu[j] + Qu[j];                     /* :272 */
+        mtm(n, n, n, A, Vxx, AtV);
+        mm(n, n, n, AtV, A, Qxx);
+        for (int i = 0; i < n * n; ++i) Qxx[i] = Qk[i] + Qxx[i];               /* :273 */
+        mtm(n, m, n, B, Vxx, BtV);
+        mm(m, n, n, BtV, A, Qux);                                              /* :274 */
+        mm(m, n, m, BtV, B, Quu);
+        for (int i = 0; i < m * m; ++i) Quu[i] = Rk[i] + Quu[i];               /* :275 */
+        for (int i = 0; i < m * m; ++i) nQuu[i] = -Quu[i];                     /* :278-279  -(Q_uu)\b = (-Q_uu)\b */
+        if (solve_small(m, nQuu, Qu, 1, k) != 0) return -(t + 1);
+        if (solve_small(m, nQuu, Qux, n, K) != 0) return -(t + 1);
+        /* :282  V_x = Q_x + K'*Q_uu*k + K'*Q_u + Q_ux'*k */
+        double KtQuu[MAXN * MAXM], v1[MAXN], v2[MAXN], v3[MAXN], t1[MAXN * MAXN], t2[MAXN * MAXN], t3[MAXN * MAXN];
+        mtm(m, n, m, K, Quu, KtQuu);
+        mm(n, m, 1, KtQuu, k, v1);
+        mtm(m, n, 1, K, Qu, v2);
+        mtm(m, n, 1, Qux, k, v3);
+        for (int i = 0; i < n; ++i) Vx[i] = ((Qx[i] + v1[i]) + v2[i]) + v3[i];
+        /* :283  V_xx = Q_xx + Q_ux'*K + K'*Q_ux + K'*Q_uu*K */
+        mtm(m, n, n, Qux, K, t1);
+        mtm(m, n, n, K, Qux, t2);
+        mm(n, m, n, KtQuu, K, t3);
+        for (int i = 0; i < n * n; ++i) Vxx[i] = ((Qxx[i] + t1[i]) + t2[i]) + t3[i];
+        for (int j = 0; j < m; ++j) k_trj[t * m + j] = k[j];                   /* :286 */
+        for (int i = 0; i < m * n; ++i) K_trj[t * m * n + i] = K[i];           /* :287 */
+        double g = 0.0, hk[MAXM], hkQ[MAXM], h = 0.0;                          /* :290-291 */
+        for (int j = 0; j < m; ++j) g += (-Qu[j]) * k[j];
+        for (int j = 0; j < m; ++j) hk[j] = 0.5 * k[j];
+        for (int j = 0; j < m; ++j) { double s = 0.0; for (int i = 0; i < m; ++i) s += hk[i] * Quu[i * m + j]; hkQ[j] = s; }
+        for (int j = 0; j < m; ++j) h += hkQ[j] * k[j];
+        ecr_g += g; ecr_h += h; ecr += g + h;                                  /* :296-298 */
+    }
+    dJ[0] = ecr; dJ[1] = ecr_g; dJ[2] = ecr_h;
+    return 0;
+}
+
+/* the warm start of a later call: ilqr_mpc.m:100-121 (states_/inputs_ moved span steps and padded from the new window;
+ * K_feedback_ keeps rows span..end (1-based) and repeats its last row) */
+void oracle_mpc_shift(int n, int m, int N, int span, const double* x_des, const double* u_des, double* states, double* inputs,
+                      double* K_fb)
+{
+    for (int t = 0; t <= N; ++t) for (int i = 0; i < n; ++i)
+        states[t * n + i] = t + span <= N ? states[(t + span) * n + i] : x_des[t * n + i];                  /* :109-110 */
+    for (int t = 0; t < N; ++t) for (int j = 0; j < m; ++j)
+        inputs[t * m + j] = t + span < N ? inputs[(t + span) * m + j] : u_des[t * m + j];                   /* :107-108 */
+    if (span > 1)
+        for (int t = 0; t < N; ++t) {                                                                       /* :120-121 */
+            const int ts = t + span - 1 < N ? t + span - 1 : N - 1;
+            for (int e = 0; e < m * n; ++e) K_fb[t * m * n + e] = K_fb[ts * m * n + e];
+        }
+}
+
+/* ilqr_mpc.solve_ilqr: ilqr_mpc.m:63-192 for one call.  states/inputs/K_fb in: the warm start (first call: the reference
+ * window itself, :73-74; later calls: after oracle_mpc_shift); out: the solution.  opts as oracle_solve; the while
+ * condition of the line search uses low_learning_rate (:158), not a literal. */
+int oracle_mpc_solve(int sys, int N, int first_call, const double* current_state, const double* x_des, const double* u_des,
+                     const double* Qk, const double* Rk, const double* QT, double dt, const double* p, int n_iterations,
+                     const double* opts, double* states, double* inputs, double* k_ff, double* K_fb, double* cost_out,
+                     int32_t* iters_out, int32_t* status_out, double* trace)
+{
+    const oracle_system* S = &SYSTEMS[sys];
+    const int n = S->n, m = S->m;
+    const double learning_speed = opts[0], low_learning_rate = opts[1], low_expected_reduction = opts[2], armijo_threshold = opts[3];
+    double* new_states = (double*)malloc(sizeof(double) * (size_t)(N + 1) * n);
+    double* new_inputs = (double*)malloc(sizeof(double) * (size_t)N * m);
+    double dJ[3];
+    int status = 0, iters = 0;
+    if (trace) for (int i = 0; i < n_iterations * 6; ++i) trace[i] = NAN;
+    if (first_call && oracle_mpc_backward(sys, N, states, inputs, x_des, u_des, Qk, Rk, QT, dt, p, k_ff, K_fb, dJ) != 0) {   /* :75-78 */
+        status = 3; goto done;
+    }
+    oracle_forward(sys, N, current_state, states, inputs, k_ff, K_fb, 0.0, dt, p, 0, new_states, new_inputs);             /* :127 */
+    double current_cost = oracle_mpc_cost(n, m, N, new_states, new_inputs, x_des, u_des, Qk, Rk, QT);                      /* :132 */
+    memcpy(states, new_states, sizeof(double) * (size_t)(N + 1) * n);                                                      /* :133-134 */
+    memcpy(inputs, new_inputs, sizeof(double) * (size_t)N * m);
+    for (int ii = 0; ii < n_iterations; ++ii) {                                                                            /* :142 */
+        ++iters;
+        if (trace) trace[ii * 6 + 0] = current_cost;
+        if (oracle_mpc_backward(sys, N, states, inputs, x_des, u_des, Qk, Rk, QT, dt, p, k_ff, K_fb, dJ) != 0) { status = 3; break; }   /* :145 */
+        if (trace) { trace[ii * 6 + 1] = dJ[0]; trace[ii * 6 + 2] = dJ[1]; trace[ii * 6 + 3] = dJ[2]; trace[ii * 6 + 4] = -1.0; }
+        if (fabs(dJ[0]) < low_expected_reduction) { status = 1; break; }                                                   /* :147 */
+        double learning_rate = 1.0;
+        int armijo_flag = 0, j = 0;
+        while (learning_rate > low_learning_rate && armijo_flag == 0) {                                                    /* :158 */
+            oracle_forward(sys, N, current_state, states, inputs, k_ff, K_fb, learning_rate, dt, p, 0, new_states, new_inputs);
+            const double new_cost = oracle_mpc_cost(n, m, N, new_states, new_inputs, x_des, u_des, Qk, Rk, QT);
+            const double cost_difference = current_cost - new_cost;                                                        /* :163 */
+            const double expected = learning_rate * dJ[1] + learning_rate * learning_rate * dJ[2];                         /* :164 */
+            armijo_flag = (cost_difference / expected > armijo_threshold);                                                 /* :165 */
+            if (armijo_flag) {
+                current_cost = new_cost;
+                memcpy(states, new_states, sizeof(double) * (size_t)(N + 1) * n);
+                memcpy(inputs, new_inputs, sizeof(double) * (size_t)N * m);
+                if (trace) { trace[ii * 6 + 4] = (double)j; trace[ii * 6 + 5] = new_cost; }
+            } else {
+                learning_rate = learning_speed * learning_rate;                                                            /* :175 */
+                ++j;
+            }
+        }
+        if (learning_rate < low_learning_rate) { status = 2; break; }                                                      /* :179 */
+    }
+    *cost_out = current_cost;
+done:
+    if (status == 3 && iters == 0) *cost_out = NAN;
+    free(new_states); free(new_inputs);
+    *iters_out = iters; *status_out = status;
+    return 0;
+}
+
+/* B independent problems (OpenMP); every array carries the leading batch axis, params/weights shared */
+int oracle_mpc_solve_batched(int sys, int64_t B, int N, int first_call, const double* current_state, const double* x_des,
+                             const double* u_des, const double* Qk, const double* Rk, const double* QT, double dt, const double* p,
+                             int n_iterations, const double* opts, double* states, double* inputs, double* k_ff, double* K_fb,
+                             double* cost, int32_t* iters, int32_t* status, double* trace, int n_threads)
+{
+    if (sys < 0 || sys >= N_SYSTEMS) return -1;
+    const int n = SYSTEMS[sys].n, m = SYSTEMS[sys].m;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t b = 0; b < B; ++b)
+        oracle_mpc_solve(sys, N, first_call, current_state + b * n, x_des + b * (int64_t)(N + 1) * n, u_des + b * (int64_t)N * m, Qk, Rk,
+                         QT, dt, p, n_iterations, opts, states + b * (int64_t)(N + 1) * n, inputs + b * (int64_t)N * m,
+                         k_ff + b * (int64_t)N * m, K_fb + b * (int64_t)N * m * n, cost + b, iters + b, status + b,
+                         trace ? trace + b * (int64_t)n_iterations * 6 : NULL);
+    return 0;
+}
+
 int oracle_num_threads(void)
 {
 #ifdef _OPENMP

@@ -168,5 +168,52 @@ def ltvlqr(system, states, inputs, Qk, Rk, QT, dt, params):
                           params)[0]
 
 
+# ---- receding-horizon tracking iLQR (matlab/smooth-ilqr/ilqr_mpc.m; restated, not pinned: MATLAB cannot run here) ----
+def mpc_cost(states, inputs, x_des, u_des, Qk, Rk, QT):
+    states, inputs = _d(states), _d(inputs)
+    N, m = inputs.shape
+    n = states.shape[1]
+    lib().oracle_mpc_cost.restype = C.c_double
+    return lib().oracle_mpc_cost(n, m, N, _p(states), _p(inputs), _p(_d(x_des)), _p(_d(u_des)), _p(_d(Qk)), _p(_d(Rk)), _p(_d(QT)))
+
+
+def mpc_backward(system, states, inputs, x_des, u_des, Qk, Rk, QT, dt, p):
+    n, m, _ = dims(system)
+    states, inputs = _d(states), _d(inputs)
+    N = inputs.shape[0]
+    k, K, dJ = np.empty((N, m)), np.empty((N, m, n)), np.empty(3)
+    rc = lib().oracle_mpc_backward(SYSTEM_IDS[system], N, _p(states), _p(inputs), _p(_d(x_des)), _p(_d(u_des)), _p(_d(Qk)),
+                                   _p(_d(Rk)), _p(_d(QT)), C.c_double(dt), _p(_d(p)), _p(k), _p(K), _p(dJ))
+    if rc != 0:
+        raise np.linalg.LinAlgError('Singular matrix')
+    return k, K, dJ
+
+
+def mpc_shift(span, x_des, u_des, states, inputs, K):
+    """in place on copies: returns the shifted (states, inputs, K) of ilqr_mpc.m:100-121"""
+    states, inputs, K = _d(states).copy(), _d(inputs).copy(), _d(K).copy()
+    N, m = inputs.shape
+    n = states.shape[1]
+    lib().oracle_mpc_shift(n, m, N, int(span), _p(_d(x_des)), _p(_d(u_des)), _p(states), _p(inputs), _p(K))
+    return states, inputs, K
+
+
+def mpc_solve_batched(system, first_call, current_state, x_des, u_des, states, inputs, k, K, Qk, Rk, QT, dt, params, n_iterations,
+                      opts=DEFAULT_OPTS, n_threads=0):
+    """one solve_ilqr call for B problems; states/inputs/k/K (B, ...) are the warm start, returned updated (copies)"""
+    n, m, _ = dims(system)
+    cur, x_des, u_des = _d(current_state).reshape(-1, n), _d(x_des), _d(u_des)
+    states, inputs, k, K = _d(states).copy(), _d(inputs).copy(), _d(k).copy(), _d(K).copy()
+    B, N = inputs.shape[0], inputs.shape[1]
+    cost_ = np.empty(B); iters = np.empty(B, np.int32); status = np.empty(B, np.int32)
+    trace = np.empty((B, n_iterations, 6))
+    rc = lib().oracle_mpc_solve_batched(SYSTEM_IDS[system], C.c_int64(B), N, int(first_call), _p(cur), _p(x_des), _p(u_des), _p(_d(Qk)),
+                                        _p(_d(Rk)), _p(_d(QT)), C.c_double(dt), _p(_d(params)), int(n_iterations), _p(_d(opts)),
+                                        _p(states), _p(inputs), _p(k), _p(K), _p(cost_), iters.ctypes.data_as(_ip),
+                                        status.ctypes.data_as(_ip), _p(trace), int(n_threads))
+    assert rc == 0
+    return dict(states=states, inputs=inputs, k=k, K=K, cost=cost_, iters=iters, status=status, trace=trace)
+
+
 def num_threads():
     return lib().oracle_num_threads()

@@ -177,7 +177,7 @@ def test_library_exports_every_declared_symbol():
     for nme in names:
         assert hasattr(handle, nme), nme
     assert sorted(_lib.SIGNATURES) == names      # the python binding covers the header exactly
-    assert _lib.lib().ilqr_abi_version() == 6
+    assert _lib.lib().ilqr_abi_version() == 7
 
 
 def test_library_host_side_calls_without_gpu():
@@ -286,6 +286,40 @@ def test_headline_batch_rounding_noise_floor(oracle):
     assert np.array_equal(a['trace'][0, :, 4], g['trace'][:, 4])
     assert rel_err(a['states'][0], g['states']) < TOL and rel_err(a['K'][0], g['K']) < TOL and rel_err(a['inputs'][0], g['inputs']) < TOL
     assert abs(a['cost'][0] - float(g['cost'])) <= TOL * abs(float(g['cost']))
+
+
+def test_mpc_restatement_reduces_to_ilqr_py(oracle):
+    """oracle_mpc_* restate matlab/smooth-ilqr/ilqr_mpc.m, which no fixture pins (MATLAB only).  Where the MATLAB algorithm
+    coincides with the pinned python one -- x_des = target_state in every row, u_des = 0, Q_k = 0, first row = the row the
+    python reference keeps -- the restatement must give the pinned functions' numbers: compute_cost exactly, backwards_pass up
+    to the one arithmetic difference of the two files (MATLAB solves Q_uu \\ Q_u, ilqr_mpc.m:278-279; python multiplies by
+    inv(Q_uu), ilqr.py:106-108), and the warm-start shift must do what ilqr_mpc.m:107-121 spells out."""
+    for system in ('acrobot', 'car', 'quadcopter'):
+        p = golden(system + '_passes')
+        N, n, m = p['inputs0'].shape[0], p['states0'].shape[1], p['inputs0'].shape[1]
+        xd, ud, Z = np.tile(p['target'], (N + 1, 1)), np.zeros((N, m)), np.zeros((n, n))
+        c = oracle.mpc_cost(p['states0'], p['inputs0'], xd, ud, Z, p['Rk'], p['QT'])
+        assert c == oracle.cost(p['states0'], p['inputs0'], p['Rk'], p['QT'], p['target'])
+        assert abs(c - float(p['cost0'])) <= 1e-13 * abs(c)
+        k, K, dJ = oracle.mpc_backward(system, p['states0'], p['inputs0'], xd, ud, p['Qk'], p['Rk'], p['QT'], float(p['dt']), p['params'])
+        tol = 1e-7 if system == 'quadcopter' else 1e-9        # (400 steps of a 4 x 4 solve-vs-inverse difference: 3e-9 on that K)
+        assert rel_err(K, p['K']) < tol and rel_err(k, p['k']) < tol and rel_err(dJ, p['dJ']) < tol           # the reference's own K, k
+        # a non-zero Q_k with targets equal to the trajectory itself adds no gradient: same gains as the python pass with that Q_k
+        Qk = 0.001 * np.eye(n)                                  # (example_acrobot_ilqr_mpc.m:13)
+        k2, K2, _ = oracle.mpc_backward(system, p['states0'], p['inputs0'], p['states0'], ud, Qk, p['Rk'], p['QT'], float(p['dt']), p['params'])
+        # (terminal target = the trajectory's own end state: V_x starts at 0 there, so compare with the python pass aimed at it)
+        k3, K3, _ = oracle.backward(system, p['states0'], p['inputs0'], p['states0'][-1], Qk, p['Rk'], p['QT'], float(p['dt']), p['params'])
+        assert rel_err(K2, K3) < tol and np.max(np.abs(k2 - k3)) <= tol * max(np.max(np.abs(k3)), np.max(np.abs(p['inputs0'])))
+    rng = np.random.default_rng(0)
+    N, n, m = 7, 3, 2
+    xs, us, K = rng.standard_normal((N + 1, n)), rng.standard_normal((N, m)), rng.standard_normal((N, m, n))
+    xd, ud = rng.standard_normal((N + 1, n)), rng.standard_normal((N, m))
+    for span in (1, 2, 3):
+        s2, u2, K2 = oracle.mpc_shift(span, xd, ud, xs, us, K)
+        assert np.array_equal(s2, np.vstack([xs[span:], xd[N + 1 - span:]]))          # ilqr_mpc.m:109-110
+        assert np.array_equal(u2, np.vstack([us[span:], ud[N - span:]]))              # :107-108
+        Kref = np.concatenate([K[span - 1:], np.repeat(K[-1:], span, axis=0)])[:N]    # :120-121 (rows span..end, 1-based)
+        assert np.array_equal(K2, Kref)
 
 
 def test_bench_launcher_starts_one_process_per_rank(tmp_path):
