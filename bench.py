@@ -123,10 +123,24 @@ def workload(name, B, seed):
         return dict(kind='solve', system=system, dt=float(g['dt']), N=N, init=g['init'][None] + rng.uniform(-0.2, 0.2, (B, n)),
                     target=g['target'], guess=_tiled(blk, B), Qk=g['Qk'], Rk=g['Rk'], QT=g['QT'], params=g['params'], n_iterations=10,
                     W=0, label='%s swing-up iLQR (the reference example, random initial states): N=%d' % (system, N))
+    if name == 'mpc':                                      # receding-horizon tracking, example_acrobot_ilqr_mpc.m:5-28
+        csv, g = golden('acrobot_csv'), golden('acrobot_solve')
+        H = 100
+        rng = np.random.default_rng(7 + seed)
+        xs = csv['states'].copy()
+        xs[0] = g['init']
+        start = 1500                                       # a window in the middle of the swing-up
+        return dict(kind='mpc', system='acrobot', dt=float(g['dt']), N=H, n_iterations=10, W=0, params=g['params'],
+                    Qk=0.001 * np.eye(4), Rk=0.01 * np.eye(1), QT=1000.0 * np.eye(4),
+                    x_des=_tiled(xs[None, start:start + H + 1], B), u_des=_tiled(csv['inputs'][None, start:start + H], B),
+                    init=xs[start] + 0.1 * rng.uniform(-1, 1, (B, 4)),
+                    label='receding-horizon tracking iLQR (matlab ilqr_mpc, example_acrobot_ilqr_mpc.m): acrobot n=4 m=1, horizon %d, '
+                          'warm-started solve_ilqr calls' % H)
     raise ValueError('unknown config %r' % name)
 
 
-DEFAULT_BATCH = {'c2': 4096, 'c3': 65536, 'c4': 131072, 'c4_w8': 131072, 'c5': 32768, 'pendulum': 131072, 'acrobot_big': 65536}
+DEFAULT_BATCH = {'c2': 4096, 'c3': 65536, 'c4': 131072, 'c4_w8': 131072, 'c5': 32768, 'pendulum': 131072, 'acrobot_big': 65536,
+                 'mpc': 65536}
 
 
 def cpu_baseline(cfg, n_iterations, sample, threads):
@@ -203,7 +217,18 @@ def spawn_ranks(n, argv, rank0_stdout=None, extra_env=None, poll_s=0.2, progress
 def make_workspace(cfg, B, device, args, want_trace=True):
     import ilqr_amd
     from ilqr_amd import _lib
-    if cfg['kind'] == 'ltvlqr':
+    if cfg['kind'] == 'mpc':
+        ws = ilqr_amd.Workspace(cfg['system'], cfg['N'], B, cfg['dt'], want_trace=want_trace, n_iterations=cfg['n_iterations'],
+                                n_alpha_parallel=args.alphas, device=device, zero_first_state=False, tracking=True)
+        ws.set_weights(cfg['Qk'], cfg['Rk'], cfg['QT'])
+        ws.upload(_lib.F_PARAMS, cfg['params'])
+        ws.upload(_lib.F_INIT, cfg['init'])
+        ws.upload(_lib.F_TARGET_STATES, cfg['x_des'])
+        ws.upload(_lib.F_TARGET_INPUTS, cfg['u_des'])
+        ws.upload(_lib.F_STATES, cfg['x_des'])              # first call: the reference window is the warm start (ilqr_mpc.m:73-74)
+        ws.upload(_lib.F_INPUTS, cfg['u_des'])
+        ws.mpc_solve(True)
+    elif cfg['kind'] == 'ltvlqr':
         ws = ilqr_amd.Workspace(cfg['system'], cfg['N'], B, cfg['dt'], device=device)
         ws.set_weights(cfg['Qk'], cfg['Rk'], cfg['QT'])
         ws.upload(_lib.F_PARAMS, cfg['params'])
@@ -230,6 +255,9 @@ def kernel_table(ws, cfg, prof, steps):
     info = ws.info()
     n, m, N = ws.n, ws.m, cfg['N']
     work = per_step_work(n, m, *SYSTEM_OPS[cfg['system']])
+    if cfg['kind'] == 'mpc':                                 # the tracking cost also reads x_des, u_des at every step
+        for key in ('bwd_bytes', 'fwd_round_bytes', 'accept_bytes'):
+            work[key] += 8 * (n + m)
     extra = {}
     if cfg['kind'] == 'ltvlqr':
         rows = [('ltvlqr', ws.B * N * work['ltv_bytes'] * steps, ws.B * N * work['ltv_flops'] * steps, 1), ('linearize', 0, 0, 1)]
@@ -285,7 +313,17 @@ def roofline_of(kern):
 
 def run_steps(ws, cfg, steps, warmup, after_step=None, barrier=None):
     """W untimed + K timed steps; returns (seconds, per-kernel HIP-event profile)"""
-    one = ws.ltvlqr if cfg['kind'] == 'ltvlqr' else ws.solve
+    mpc_rng = np.random.default_rng(99)
+
+    def mpc_call():
+        # a later solve_ilqr call: a new measured state (the window's first state plus a fresh disturbance: 32 B per problem
+        # over PCIe, the only host data of the call), the warm start moved one step, then the solve
+        from ilqr_amd import _lib
+        ws.upload(_lib.F_INIT, cfg['x_des'][:, 0] + 0.1 * mpc_rng.uniform(-1, 1, cfg['init'].shape))
+        ws.mpc_shift(1)
+        ws.mpc_solve(False)
+
+    one = {'ltvlqr': ws.ltvlqr, 'mpc': mpc_call}.get(cfg['kind'], ws.solve)
 
     def step():
         one()
@@ -317,13 +355,14 @@ def extra_config(name, args):
     kern, info, extra = kernel_table(ws, cfg, prof, steps)
     roof, dominant = roofline_of(kern)
     out = {'workload': '%s, B=%d on one GPU%s' % (cfg['label'], B, '' if cfg['kind'] == 'ltvlqr' else ', %d iterations' % cfg['n_iterations']),
-           'value': round(B * steps / elapsed, 1), 'unit': 'gain schedules/s' if cfg['kind'] == 'ltvlqr' else 'solves/s',
+           'value': round(B * steps / elapsed, 1),
+           'unit': {'ltvlqr': 'gain schedules/s', 'mpc': 'solve_ilqr calls/s'}.get(cfg['kind'], 'solves/s'),
            'ms_per_step': round(1e3 * elapsed / steps, 3), 'steps': steps, 'pipeline': info['pipeline'], 'ls_widths': info['ls_widths'],
            'hbm_resident_GB': round(info['hbm_bytes'] / 1e9, 2), 'setup_s': round(t_setup, 1), 'roofline': roof,
            'kernels_ms_per_pass': {k_: round(v['ms_per_pass'], 3) for k_, v in kern.items()},
            'kernels_hbm_frac': {k_: round(v['gbs'] / HBM_PEAK_GBS, 4) for k_, v in kern.items() if v['gbs'] > 0},
            'kernels_fp64_frac': {k_: round(v['tflops'] / FP64_PEAK_TFLOPS, 4) for k_, v in kern.items() if v['tflops'] > 0}}
-    if cfg['kind'] == 'solve':
+    if cfg['kind'] in ('solve', 'mpc'):
         st = extra['status']
         out['exit_status_counts'] = {n_: int((st == s).sum()) for s, n_ in ((0, 'max_iter'), (1, 'optimal'), (2, 'low_learning_rate'), (3, 'numerical'))}
         out['mean_ref_trials_per_linesearch'] = round(float(extra['ref_trials'].sum()) / max(int(extra['ran_ls'].sum()), 1), 2)
@@ -453,15 +492,16 @@ def main():
                     note='peak = FP64 vector rate (= FP64 MFMA rate on MI355X); MFMA itself is not used, see DESIGN.md')
 
     value = total * args.steps / elapsed
-    unit = 'gain schedules/s' if cfg['kind'] == 'ltvlqr' else 'solves/s'
+    unit = {'ltvlqr': 'gain schedules/s', 'mpc': 'solve_ilqr calls/s'}.get(cfg['kind'], 'solves/s')
     out = {
-        'metric': 'iLQR solves/sec (fixed iters, batched)' if cfg['kind'] == 'solve' else 'LTV-LQR gain schedules/sec (batched)',
+        'metric': {'solve': 'iLQR solves/sec (fixed iters, batched)', 'ltvlqr': 'LTV-LQR gain schedules/sec (batched)',
+                   'mpc': 'receding-horizon iLQR solves/sec (warm-started, batched)'}[cfg['kind']],
         'value': round(value, 2), 'unit': unit,
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
         'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': '%s, %s%s' % (cfg['label'], ('ONE batch of %d problems split over %d GPU(s)' % (total, world)) if strong
                                              else 'B=%d problems per GPU' % B,
-                                             ', %d iterations, reference line search + stop tests active' % cfg['n_iterations'] if cfg['kind'] == 'solve' else ''),
+                                             ', %d iterations, reference line search + stop tests active' % cfg['n_iterations'] if cfg['kind'] != 'ltvlqr' else ''),
                    'problems_per_gpu': B, 'problems_total': total, 'n_timesteps': N, 'n_alpha_parallel': W, 'pipeline': info['pipeline'],
                    'sharding': 'by problem index, %d rank(s), all-gather of {cost,iters,status} only (%s)'
                                % (world, 'RCCL' if args.backend == 'nccl' else 'gloo rehearsal')},
@@ -472,7 +512,7 @@ def main():
         out['ranks_seen'] = world
         out['gathered_records'] = int(gathered['rec'].shape[0])
         out['gathered_status_counts'] = {_lib.STATUS_NAMES[s]: int((gathered['rec'][:, 2] == s).sum()) for s in range(4)}
-    if cfg['kind'] == 'solve':
+    if cfg['kind'] in ('solve', 'mpc'):
         status, trace = extra['status'], extra['trace']
         out['config']['n_iterations'] = cfg['n_iterations']
         # one backward + line search + accept pass, from the wall clock of the step (the accept step of iteration i and the
@@ -487,7 +527,7 @@ def main():
             g = golden('acrobot_solve')
             k_it = min(cfg['n_iterations'], g['trace'].shape[0])
             out['check_problem0_cost_rel_err'] = float(np.max(np.abs(trace[0, :k_it, 0] - g['trace'][:k_it, 0]) / np.abs(g['trace'][:k_it, 0])))
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu and world == 1 and cfg['kind'] == 'solve':
             threads = min(16, os.cpu_count() or 1)
             sample = min(args.cpu_sample, B)
             v, secs, r = cpu_baseline(cfg, cfg['n_iterations'], sample, threads)
@@ -505,7 +545,7 @@ def main():
     ws.close()
     if world == 1 and not args.no_extra and args.config == 'c2' and not strong and args.batch in (0, DEFAULT_BATCH['c2']):
         out['extra_configs'] = {}
-        for name in ('c3', 'c4', 'c4_w8', 'c5', 'pendulum', 'acrobot_big'):
+        for name in ('c3', 'c4', 'c4_w8', 'c5', 'pendulum', 'acrobot_big', 'mpc'):
             try:
                 out['extra_configs'][name] = extra_config(name, args)
             except Exception as e:                             # an extra block must never cost the headline line
