@@ -52,7 +52,8 @@ def per_step_work(n, m, f_ops, ab_ops):
         ltv_flops=4 * n**3 + 8 * n * n * m + 4 * n * m * m + 2 * m**3 + ab_ops)
 
 
-SYSTEM_OPS = {'pendulum': (12, 8), 'cartpole': (31, 63), 'acrobot': (93, 189), 'quadcopter': (134, 164)}
+SYSTEM_OPS = {'pendulum': (12, 8), 'cartpole': (31, 63), 'acrobot': (93, 189), 'quadcopter': (134, 164),
+              'floating_base': (402, 2964)}     # (operations of the generated f, and of A + B, after CSE)
 
 
 def golden(name):
@@ -114,6 +115,15 @@ def workload(name, B, seed):
         return dict(kind='solve', system='quadcopter', dt=float(g['dt']), N=N, init=np.zeros((B, 12)), target=target,
                     guess=_tiled(g['guess'][None], B), Qk=g['Qk'], Rk=g['Rk'], QT=g['QT'], params=g['params'], n_iterations=10, W=0,
                     label='quadcopter iLQR (BASELINE configs[4], one GPU of 8): n=12 m=4 N=%d' % N)
+    if name == 'floating_base':                            # 12 states, 12 inputs (synthetic stance change, see
+        g = golden('floating_base_solve')                  # tools/make_golden.py cfg_floating_base), per-problem targets
+        N = g['guess'].shape[0]
+        rng = np.random.default_rng(9 + seed)
+        target = np.tile(g['target'], (B, 1))
+        target[:, :6] += rng.uniform(-0.05, 0.05, (B, 6))
+        return dict(kind='solve', system='floating_base', dt=float(g['dt']), N=N, init=np.zeros((B, 12)), target=target,
+                    guess=_tiled(g['guess'][None], B), Qk=g['Qk'], Rk=g['Rk'], QT=g['QT'], params=g['params'], n_iterations=10, W=0,
+                    label='floating-base trunk iLQR (symbolic_dynamics_floating_base.m, synthetic stance change): n=12 m=12 N=%d' % N)
     if name in ('pendulum', 'acrobot_big'):                # the north star's large batches of the two example problems
         system = 'pendulum' if name == 'pendulum' else 'acrobot'
         g = golden(system + '_solve')
@@ -140,7 +150,7 @@ def workload(name, B, seed):
 
 
 DEFAULT_BATCH = {'c2': 4096, 'c3': 65536, 'c4': 131072, 'c4_w8': 131072, 'c5': 32768, 'pendulum': 131072, 'acrobot_big': 65536,
-                 'mpc': 65536}
+                 'mpc': 65536, 'floating_base': 16384}
 
 
 def cpu_baseline(cfg, n_iterations, sample, threads):
@@ -545,7 +555,7 @@ def main():
     ws.close()
     if world == 1 and not args.no_extra and args.config == 'c2' and not strong and args.batch in (0, DEFAULT_BATCH['c2']):
         out['extra_configs'] = {}
-        for name in ('c3', 'c4', 'c4_w8', 'c5', 'pendulum', 'acrobot_big', 'mpc'):
+        for name in ('c3', 'c4', 'c4_w8', 'c5', 'pendulum', 'acrobot_big', 'mpc', 'floating_base'):
             try:
                 out['extra_configs'][name] = extra_config(name, args)
             except Exception as e:                             # an extra block must never cost the headline line

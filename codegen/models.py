@@ -13,8 +13,8 @@ reference lambdifies:
   same 15-digit literals when printed)
 * cartpole   -- spec: matlab/smooth-ilqr/symbolic_dynamics_cartpole.m:2-22
 * quadcopter -- spec: matlab/smooth-ilqr/symbolic_dynamics_quadcopter.m:3-51
-* car, double_integrator, double_pendulum -- specs: matlab/smooth-ilqr/symbolic_dynamics_{car,double_integrator,
-  double_pendulum}.m
+* car, double_integrator, double_pendulum, floating_base -- specs: matlab/smooth-ilqr/symbolic_dynamics_{car,
+  double_integrator,double_pendulum,floating_base}.m
 
 The MATLAB files are specifications only (read as text; nothing here executes
 them).  This module needs sympy and is used by ``codegen/gen_dynamics.py`` and
@@ -184,8 +184,50 @@ def double_pendulum():
     return _two_link_arm('double_pendulum', both_joints_actuated=True)
 
 
+def floating_base():
+    """spec: matlab/smooth-ilqr/symbolic_dynamics_floating_base.m:2-92 -- a single rigid body (quadruped trunk) driven by the
+    ground-reaction forces of four feet: 12 states [position, roll-pitch-yaw, linear velocity, world angular velocity],
+    12 inputs [F_1; F_2; F_3; F_4], 17 parameters [I_xx I_yy I_zz m g, foot positions 1..4] (:81-85).  The same sequence as
+    the .m file: world inertia rot' I rot and its simplified inverse (:55-57), body rates from the simplified inverse of the
+    rate map (:60-64), angular acceleration from the feet's wrenches (:67, skew.m), gravity added as [0;0;g] (:70-72)."""
+    x, y, z, x_dot, y_dot, z_dot, phi, theta, psi = sp.symbols('x y z x_dot y_dot z_dot phi theta psi', real=True)
+    phi_dot_world, theta_dot_world, psi_dot_world, dt = sp.symbols('phi_dot_world theta_dot_world psi_dot_world dt', real=True)
+    feet = [Matrix(sp.symbols('foot_pos_%dx foot_pos_%dy foot_pos_%dz' % (i, i, i), real=True)) for i in (1, 2, 3, 4)]
+    F = [Matrix(sp.symbols('F_%dx F_%dy F_%dz' % (i, i, i), real=True)) for i in (1, 2, 3, 4)]
+    I_xx, I_yy, I_zz, m, g = sp.symbols('I_xx I_yy I_zz m g', real=True)
+    robot_pos = Matrix([x, y, z])
+    robot_orientation = Matrix([phi, theta, psi])
+    robot_lin_vel = Matrix([x_dot, y_dot, z_dot])
+    robot_ang_vel_world = Matrix([phi_dot_world, theta_dot_world, psi_dot_world])
+    states = Matrix([robot_pos, robot_orientation, robot_lin_vel, robot_ang_vel_world])
+    r = [robot_pos - fp for fp in feet]
+    inputs = Matrix([F[0], F[1], F[2], F[3]])
+    sin, cos = sp.sin, sp.cos
+    rot_roll = Matrix([[1, 0, 0], [0, cos(phi), -sin(phi)], [0, sin(phi), cos(phi)]])
+    rot_pitch = Matrix([[cos(theta), 0, sin(theta)], [0, 1, 0], [-sin(theta), 0, cos(theta)]])
+    rot_yaw = Matrix([[cos(psi), -sin(psi), 0], [sin(psi), cos(psi), 0], [0, 0, 1]])
+    rot_mat = rot_yaw * rot_pitch * rot_roll
+    I_body = sp.diag(I_xx, I_yy, I_zz)
+    # I_hat = rot' I rot and I_hat_inv = simplify(inv(I_hat)) in the .m file (:55-57).  MATLAB's simplifier is not available and
+    # sympy's does not finish on the symbolic 3 x 3 inverse within half an hour; rot is orthogonal, so the inverse is written
+    # down directly -- the same function, as an expression neither simplifier would need to touch.
+    I_hat_inv = rot_mat.T * sp.diag(1 / I_xx, 1 / I_yy, 1 / I_zz) * rot_mat
+    rot_mat_vel = Matrix([[cos(theta) * cos(psi), -sin(psi), 0], [cos(theta) * sin(psi), cos(psi), 0], [0, 0, 1]])
+    ang_vel_body = sp.simplify(rot_mat_vel.inv() * robot_ang_vel_world)
+
+    def skew(w):
+        return Matrix([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+
+    ang_accel_world = I_hat_inv * (skew(r[0]) * F[0] + skew(r[1]) * F[1] + skew(r[2]) * F[2] + skew(r[3]) * F[3])   # (:67, unsimplified)
+    gravity_vec = Matrix([0, 0, g])
+    linear_accel = 1 / m * (F[0] + F[1] + F[2] + F[3]) + gravity_vec
+    f = Matrix([robot_lin_vel, ang_vel_body, linear_accel, ang_accel_world])
+    parameters = Matrix([I_xx, I_yy, I_zz, m, g] + [c for fp in feet for c in fp])
+    return _finish('floating_base', states, inputs, dt, parameters, f)
+
+
 BUILDERS = {'pendulum': pendulum, 'acrobot': acrobot, 'cartpole': cartpole, 'quadcopter': quadcopter, 'car': car,
-            'double_integrator': double_integrator, 'double_pendulum': double_pendulum}
+            'double_integrator': double_integrator, 'double_pendulum': double_pendulum, 'floating_base': floating_base}
 # system ids are part of the C-ABI (include/ilqr_hip.h)
 SYSTEM_IDS = {'pendulum': 0, 'acrobot': 1, 'cartpole': 2, 'quadcopter': 3, 'car': 4, 'double_integrator': 5,
-              'double_pendulum': 6}
+              'double_pendulum': 6, 'floating_base': 7}

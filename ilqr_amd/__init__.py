@@ -17,10 +17,11 @@ from .tracking import tracking_rollout
 from .trajectory_io import load_trajectory_csv, load_trajectory_mat, save_trajectory_csv, save_trajectory_mat
 from .symbolic_dynamics import (CompiledDynamics, symbolic_dynamics_acrobot, symbolic_dynamics_car,
                                 symbolic_dynamics_cartpole, symbolic_dynamics_double_integrator,
-                                symbolic_dynamics_double_pendulum, symbolic_dynamics_pendulum,
+                                symbolic_dynamics_double_pendulum, symbolic_dynamics_floating_base,
+                                symbolic_dynamics_pendulum,
                                 symbolic_dynamics_quadcopter)
 
 __all__ = ['ilqr', 'ilqr_mpc', 'ltvlqr', 'tracking_rollout', 'save_trajectory_csv', 'load_trajectory_csv',
            'save_trajectory_mat', 'load_trajectory_mat', 'symbolic_dynamics_pendulum', 'symbolic_dynamics_acrobot', 'symbolic_dynamics_cartpole',
            'symbolic_dynamics_quadcopter', 'symbolic_dynamics_car', 'symbolic_dynamics_double_integrator',
-           'symbolic_dynamics_double_pendulum', 'CompiledDynamics', 'Workspace', 'IlqrHipError', 'lib']
+           'symbolic_dynamics_double_pendulum', 'symbolic_dynamics_floating_base', 'CompiledDynamics', 'Workspace', 'IlqrHipError', 'lib']

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ILQR_HIP_LIB') or os.path.join(_HERE, 'libilqr_hip.so')
 
 SYSTEM_IDS = {'pendulum': 0, 'acrobot': 1, 'cartpole': 2, 'quadcopter': 3, 'car': 4, 'double_integrator': 5,
-              'double_pendulum': 6}
+              'double_pendulum': 6, 'floating_base': 7}
 STATUS_NAMES = {0: 'max_iter', 1: 'optimal', 2: 'low_learning_rate', 3: 'numerical'}
 
 # fields of the device-resident workspace (include/ilqr_hip.h)

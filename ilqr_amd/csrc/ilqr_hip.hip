@@ -68,6 +68,7 @@
 #include "dynamics/car.h"
 #include "dynamics/double_integrator.h"
 #include "dynamics/double_pendulum.h"
+#include "dynamics/floating_base.h"
 // The quadcopter comes last: its dynamics use the LIBRARY's sin/cos/tan.  Its 21-iteration example solve amplifies
 // last-bit rounding most: with the fast pair above (0.79 ulp) the final K is 9.2e-9 from the
 // reference, with ocml's (as accurate as the glibc the reference runs on) 3.8e-9 -- a 2.6x margin to the 1e-8 bar for
@@ -204,6 +205,7 @@ int with_system(int sys, F&& fn)
         case 4: return fn(Sys_car{});
         case 5: return fn(Sys_double_integrator{});
         case 6: return fn(Sys_double_pendulum{});
+        case 7: return fn(Sys_floating_base{});
     }
     return fail(-2, "unknown system id %d", sys);
 }
@@ -243,7 +245,12 @@ void launch_ls(hipStream_t st, const KArgs& a, bool ckpt, bool track = false)
     const long long waves = a.n_tiles * W;          // tiles * 64 problems * W lanes / 64
     constexpr int wpb = W == 64 ? 8 : 4;
     const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
-    if (track) {
+    if constexpr (!lane_recursion_ok<S>) {
+        // m > 4: the split schedule only, and widths the staged rollout's LDS records fit (ilqr_ws_create sees to both)
+        if constexpr (W >= 16) hipLaunchKernelGGL((k_linesearch<S, W, true>), dim3(grid), dim3(64 * wpb), 0, st, a);
+        return;
+    }
+    else if (track) {
         // tracking cost: fused schedule only, line-search widths 8 / 16 / 32 (ilqr_ws_create maps the others onto these)
         if constexpr (W == 8 || W == 16 || W == 32) hipLaunchKernelGGL((k_linesearch<S, W, false, true>), dim3(grid), dim3(64 * wpb), 0, st, a);
     }
@@ -428,7 +435,7 @@ int ws_riccati(ilqr_ws* ws, int it, int sub = -1)
         else if (ws->quad) {
             if constexpr (T::n <= 4) hipLaunchKernelGGL(k_riccati_quad<T>, dim3((unsigned)(a.n_tiles * 4)), dim3(64), 0, st, a);
         }
-        else hipLaunchKernelGGL(k_riccati<T>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+        else if constexpr (lane_recursion_ok<T>) hipLaunchKernelGGL(k_riccati<T>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
     }, sub);
 }
 int ws_accept_lin(ilqr_ws* ws, int it, int sub = -1)
@@ -505,8 +512,10 @@ int ws_rollout(ilqr_ws* ws, int sub = -1)
 int ws_backward(ilqr_ws* ws, int it, int sub = -1)
 {
     return run_pass(ws, KID_BACKWARD, it, "k_backward", [&](auto S, const KArgs& a, hipStream_t st) {
-        if (ws->d.tracking) hipLaunchKernelGGL((k_backward<decltype(S), true>), dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL(k_backward<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+        if constexpr (lane_recursion_ok<decltype(S)>) {
+            if (ws->d.tracking) hipLaunchKernelGGL((k_backward<decltype(S), true>), dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+            else hipLaunchKernelGGL(k_backward<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+        }
     }, sub);
 }
 // One launch per round of W trials.  Round 0 runs every active problem in place; a problem none of whose W trials passed
@@ -707,7 +716,7 @@ int ilqr_system_lookup(const char* name, int32_t* n, int32_t* m, int32_t* np)
             ilqr_system_dims(i, n, m, np);
             return i;
         }
-    return fail(-2, "unknown system '%s' (compiled in: pendulum, acrobot, cartpole, quadcopter, car, double_integrator, double_pendulum)", name);
+    return fail(-2, "unknown system '%s' (compiled in: pendulum, acrobot, cartpole, quadcopter, car, double_integrator, double_pendulum, floating_base)", name);
 }
 
 int ilqr_dynamics_eval(int32_t sys, int32_t which, int64_t count, const double* x, const double* u, double dt,
@@ -820,6 +829,16 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
             }
             if (n_r > 0 && cov >= n_trials) ws->ls_rounds_n = n_r;
         }
+        if (ws->m > 4) {   // the staged rollout's records (n + 2m + mn doubles per problem and step) fit LDS from 16 lanes per problem up
+            int cov = 0, n_r = 0;
+            while (cov < n_trials) {
+                const int w = ws->ls_width[n_r < ws->ls_rounds_n ? n_r : ws->ls_rounds_n - 1];
+                ws->ls_width[n_r++] = w < 16 ? 16 : w;
+                cov += ws->ls_width[n_r - 1];
+            }
+            ws->ls_rounds_n = n_r;
+            if (ws->W < 16) ws->W = 16;
+        }
     }
     // pipeline: with few tiles the horizon-sequential kernels occupy one wave per tile and leave most of the 1024 SIMDs
     // idle, so the parallel parts (accept re-roll, Jacobians) are split off; large batches fill the chip either way and
@@ -829,6 +848,13 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
     // Riccati recursion: one lane per problem while V_xx fits its registers (n <= 4), a lane group with LDS hand-offs
     // beyond (always through the split schedule, which provides LIN); riccati = 1 / 2 forces lane / group
     ws->grp = !d->tracking && (d->riccati == 2 || (d->riccati == 0 && ws->n > 4));
+    if (ws->m > 4 && !ws->grp) {
+        // one lane cannot hold Q_uu, its inverse and K beyond 4 inputs: only the lane-group recursion is compiled for them
+        const int trk = d->tracking;
+        delete ws;
+        return fail(-1, trk ? "the tracking cost (ilqr_mpc) is compiled for systems with at most 4 inputs"
+                            : "systems with more than 4 inputs run the lane-group recursion only (riccati = 0 or 2)");
+    }
     if (ws->grp) ws->split = 1;
     // four lanes per problem (k_riccati_quad): a shorter instruction chain per step on a chip the lane kernel leaves
     // idle.  Measured on the acrobot (N = 3000): 4096 problems 1.87 -> 1.44 ms, 8192 1.88 -> 1.62, 12 288 1.93 -> 2.15
@@ -1028,7 +1054,7 @@ int ilqr_ws_rollout(ilqr_ws* ws) { return ws_rollout(ws); }
 int ilqr_ws_cost(ilqr_ws* ws)
 {
     return run_pass(ws, KID_COST, 0, "k_cost", [&](auto S, const KArgs& a, hipStream_t st) {
-        if (ws->d.tracking) hipLaunchKernelGGL((k_cost<decltype(S), true>), dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+        if (ws->d.tracking) { if constexpr (lane_recursion_ok<decltype(S)>) hipLaunchKernelGGL((k_cost<decltype(S), true>), dim3((unsigned)a.n_tiles), dim3(64), 0, st, a); }
         else hipLaunchKernelGGL(k_cost<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
     });
 }
@@ -1057,7 +1083,7 @@ int ilqr_ws_forward(ilqr_ws* ws, int32_t with_cost)
     return run_pass(ws, KID_FORWARD, 0, "k_forward", [&](auto S, const KArgs& a0, hipStream_t st) {
         KArgs a = a0;
         a.XO = ws->XO; a.UO = ws->UO;
-        if (ws->d.tracking) hipLaunchKernelGGL((k_forward<decltype(S), false, true>), dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+        if (ws->d.tracking) { if constexpr (lane_recursion_ok<decltype(S)>) hipLaunchKernelGGL((k_forward<decltype(S), false, true>), dim3((unsigned)a.n_tiles), dim3(64), 0, st, a); }
         else hipLaunchKernelGGL((k_forward<decltype(S), false>), dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
     });
 }
@@ -1099,7 +1125,7 @@ int ilqr_ws_mpc_solve(ilqr_ws* ws, int32_t first_call)
     rc = run_pass(ws, KID_FORWARD, 0, "k_forward<tracking>", [&](auto S, const KArgs& a0, hipStream_t st) {
         KArgs a = a0;
         a.XO = ws->X; a.UO = ws->U; a.fwd_to_cost = 1;
-        hipLaunchKernelGGL((k_forward<decltype(S), false, true>), dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+        if constexpr (lane_recursion_ok<decltype(S)>) hipLaunchKernelGGL((k_forward<decltype(S), false, true>), dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
     });
     if (rc) return rc;
     for (int it = 0; it < ws->d.n_iterations; ++it) {                // :142-184
@@ -1120,7 +1146,7 @@ int ilqr_ws_ltvlqr(ilqr_ws* ws)
         });
     }
     return run_pass(ws, KID_LTVLQR, 0, "k_ltvlqr", [&](auto S, const KArgs& a, hipStream_t st) {
-        hipLaunchKernelGGL(k_ltvlqr<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
+        if constexpr (lane_recursion_ok<decltype(S)>) hipLaunchKernelGGL(k_ltvlqr<decltype(S)>, dim3((unsigned)a.n_tiles), dim3(64), 0, st, a);
     });
 }
 

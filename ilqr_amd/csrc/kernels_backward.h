@@ -290,8 +290,13 @@ struct Grp {
     static constexpr int GL = 16;                       // one DPP row
     static constexpr int P = TILE / GL;                 // problems per wave
     static constexpr int LD = n + 1;                    // padded leading dimension of the transpose buffers
-    static constexpr int oT = 0, oAT = oT + n * LD, SLOT = ((oAT + n * LD + 1) | 1);
+    // m > 4 (floating base: 12 inputs): Q_uu no longer fits every lane's registers m x m -- lane l owns COLUMN l of Q_uu,
+    // the factorisation and the solves for K and k run distributed over the row of lanes (see the kernel), and the
+    // columns of B_t come through a third transpose buffer
+    static constexpr bool BIGM = m > 4;
+    static constexpr int oT = 0, oAT = oT + n * LD, oBT = oAT + n * LD, SLOT = (((BIGM ? oBT + m * LD : oAT + n * LD) + 1) | 1);
     static_assert(n <= GL, "k_riccati_grp: one lane per state");
+    static_assert(!BIGM || m < GL, "k_riccati_grp: one lane per input and one spare lane for the feed-forward solve");
 };
 
 // index of dense entry e of A (or B) in the step's LIN row; -1 structural zero, -2 structural one, -3 exactly dt (not stored)
@@ -629,7 +634,7 @@ __global__ void __launch_bounds__(64) k_riccati_quad(const KArgs a)
 // LTV = true: the ltvlqr recursion (ltvlqr.py:14-27) on the same lane mapping -- no V_x, k or expected reductions, the
 // value update is P = (Q + A'PA) - (A'PB) G^-1 (B'PA) with A'PB formed from the rows of A'P as the reference does.
 template <class S, bool LTV = false>
-__global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KArgs a)
+__global__ void __launch_bounds__(64, Grp<S>::BIGM ? 1 : RICCATI_GRP_WAVES) k_riccati_grp(const KArgs a)
 {
     using G = Grp<S>;
     constexpr int n = S::n, m = S::m, GL = G::GL, P = G::P, NL = Lin<S>::n_lin, LD = G::LD;
@@ -651,7 +656,7 @@ __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KAr
     // where row cc of A_t / B_t sits in a LIN record: byte offsets of the general entries (structural zeros and ones
     // load a harmless valid entry instead; their constants are written to the transpose buffer once, below)
     int aoff[n], boff[m];
-    unsigned amask = 0, adt = 0, bdt = 0;              // adt / bdt: entries of this lane's row that are exactly dt (not stored)
+    unsigned amask = 0, bmask = 0, adt = 0, bdt = 0;   // adt / bdt: entries of this lane's row that are exactly dt (not stored)
 #pragma unroll
     for (int i = 0; i < n; ++i) {
         const int q = lin_index<S, false>(cc * n + i);
@@ -665,14 +670,23 @@ __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KAr
         const int q = lin_index<S, true>(cc * m + l);
         boff[l] = (q > 0 ? q : 0) * (TILE * (int)sizeof(double));
         bdt |= (q == -3 ? 1u : 0u) << l;
+        bmask |= (q >= 0 ? 1u : 0u) << l;
+        if constexpr (G::BIGM) { if (row && q < 0) s[G::oBT + l * LD + c] = q == -2 ? 1.0 : (q == -3 ? a.dt : 0.0); }
     }
     // columns of A / B that hold a dt entry in some row (compile time): only those pay the per-lane patch below
     constexpr auto a_col_dt = [](int i) { bool v = false; for (int r = 0; r < n; ++r) v = v || S::a_is_dt(r * n + i); return v; };
     constexpr auto b_col_dt = [](int l) { bool v = false; for (int r = 0; r < n; ++r) v = v || S::b_is_dt(r * m + l); return v; };
-    double Rk[m * m], Vc[n], vx;
+    double Rk[G::BIGM ? 1 : m * m], Vc[n], vx;
     double* sQk = sh + P * G::SLOT;                                                    // Q_k, shared by the rows
     for (int e = lane; e < n * n; e += TILE) sQk[e] = a.WTS[e];
-    load_uniform<m * m>(a.WTS + n * n, Rk);
+    const int cm = c < m ? c : m - 1;                   // BIGM: the column of Q_uu (and of B_t, R_k) this lane owns
+    double Rcol[G::BIGM ? m : 1], Rrow[G::BIGM ? m : 1];
+    if constexpr (G::BIGM) {
+#pragma unroll
+        for (int l = 0; l < m; ++l) { Rcol[l] = a.WTS[n * n + l * m + cm]; Rrow[l] = a.WTS[n * n + cm * m + l]; }
+    } else {
+        load_uniform<m * m>(a.WTS + n * n, Rk);
+    }
     const double* QT = a.WTS + n * n + m * m;
 #pragma unroll
     for (int r = 0; r < n; ++r) Vc[r] = QT[r * n + cc];                                // :67 column j of Q_T
@@ -745,13 +759,137 @@ __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KAr
                 s[G::oT + i * LD + c] = AtV[i];
                 if ((amask >> i) & 1u) s[G::oAT + i * LD + c] = Ar[i];
             }
+            if constexpr (G::BIGM) {
+#pragma unroll
+                for (int l = 0; l < m; ++l) if ((bmask >> l) & 1u) s[G::oBT + l * LD + c] = Br[l];
+            }
         }
         __syncthreads();
         // ---- gains (every lane: Q_uu, Q_u, the inverse, k; lane i: column i of Q_ux and K, Q_x[i]).  Done before the
         // row phase so that Q_uu and its inverse (2 m^2 doubles) are dead when the rows of A^T V_xx come into registers.
         double Qux[m], Qu[m], k[m], Kc[m], KtQuu[m], g = 0.0, h = 0.0;
-        double Gi[LTV ? m * m : 1];                                                    // ltvlqr keeps G^-1 for the P update
-        {
+        double Gi[LTV && !G::BIGM ? m * m : 1];                                        // ltvlqr keeps G^-1 for the P update
+        double wl[LTV ? m : 1];                                                        // ltvlqr: (A'PB G^-1)[i][:]
+        if constexpr (G::BIGM) {
+            // ---- m > 4.  Lane l (< m) owns column l of Q_uu; lane i (< n) owns column i of Q_ux and solves for column i of
+            // K; lane m, a spare one, solves for k.  Q_uu = L D L' is factorised right-looking: at step j lane j's pivot and
+            // its column come to every lane by row broadcasts (the whole of L ends up replicated, 66 doubles for m = 12),
+            // every lane updates its own column and -- forward substitution folded in -- its own right-hand side; then
+            // D^-1 and the backward substitution with L'.  The reference multiplies by inv(Q_uu) (ilqr.py:106-108); this
+            // solves with the factors: the same gains up to rounding, as the Cholesky-based inverse for m <= 4.
+            // np.linalg.inv's rule is kept as far as a factorisation without pivoting can: only an exactly zero pivot is an
+            // error (status 3).  An indefinite Q_uu is solved all the same (D then has negative entries; as accurate as its
+            // leading minors are conditioned), and a NaN Q_uu yields NaN gains, so that a diverged problem ends as it does in
+            // the reference -- every Armijo test False, 'low learning rate'.
+            double Acol[n], Bcol[n], qc[m], qo[m], Qx = 0.0, quc = 0.0;
+#pragma unroll
+            for (int r = 0; r < n; ++r) { Acol[r] = s[G::oAT + cc * LD + r]; Bcol[r] = s[G::oBT + cm * LD + r]; }
+#pragma unroll
+            for (int l = 0; l < m; ++l) { Qux[l] = 0.0; qc[l] = 0.0; }
+            static_for<0, n>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+#pragma unroll
+                for (int l = 0; l < m; ++l) fmac_row<r>(Qux[l], BtV[l], Acol[r]);       // :101 (B^T V_xx)[l][r] * A[r][i]
+#pragma unroll
+                for (int l = 0; l < m; ++l) fmac_row<r>(qc[l], BtV[l], Bcol[r]);        // :102 (B^T V_xx)[l][r] * B[r][c]
+                fmac_row<r>(Qx, vx, Acol[r]);                                          // :99
+                fmac_row<r>(quc, vx, Bcol[r]);                                         // :100 B[r][c] * V_x[r]
+            });
+            {
+                double lu = 0.0;                                                       // :93 l_u = R_k u, entry c
+#pragma unroll
+                for (int l2 = 0; l2 < m; ++l2) lu = __builtin_fma(Rrow[l2], u[l2], lu);
+                quc = lu + quc;
+            }
+#pragma unroll
+            for (int l = 0; l < m; ++l) {
+                qc[l] = Rcol[l] + qc[l];
+                if (l == cm) qc[l] += a.quu_reg;
+                qo[l] = qc[l];                                                         // Q_uu[:, c] as it is, for :116 and :124-125
+            }
+            static_for<0, m>([&](auto lc) { constexpr int l = decltype(lc)::value; Qu[l] = bcast_row<l>(quc); });
+            double b1[m], b2[LTV ? m : 1], rinv[m], Lr[m * m];
+#pragma unroll
+            for (int l = 0; l < m; ++l) b1[l] = c == m ? Qu[l] : Qux[l];
+            if constexpr (LTV) {                                                       // second right-hand side: (A'PB)[i][:]
+                double Ri0[n];
+#pragma unroll
+                for (int r = 0; r < n; ++r) Ri0[r] = s[G::oT + cc * LD + r];
+#pragma unroll
+                for (int l = 0; l < m; ++l) b2[l] = 0.0;
+                static_for<0, n>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    static_for<0, m>([&](auto lc) {
+                        constexpr int l = decltype(lc)::value;
+                        constexpr char kd = S::B_pat[r * m + l];
+                        if constexpr (kd == 'x') fmac_row<r>(b2[l], Br[l], Ri0[r]);
+                        else if constexpr (kd == '1') b2[l] = b2[l] + Ri0[r];
+                    });
+                });
+            }
+            static_for<0, m>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const double d = bcast_row<j>(qc[j]);                                  // pivot D[j]
+                ok = ok && d != 0.0;
+                const double ri = 1.0 / d;
+                rinv[j] = ri;
+                double lcj = 0.0;                                                      // L[c][j] for this lane's column c > j
+                static_for<j + 1, m>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    const double lij = bcast_row<j>(qc[i]) * ri;                       // L[i][j], the same in every lane
+                    Lr[i * m + j] = lij;
+                    lcj = i == cm ? lij : lcj;
+                    b1[i] = __builtin_fma(-lij, b1[j], b1[i]);                          // forward substitution, column-wise
+                    if constexpr (LTV) b2[i] = __builtin_fma(-lij, b2[j], b2[i]);
+                });
+                const double w = lcj * d;
+                static_for<j + 1, m>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    qc[i] = __builtin_fma(-Lr[i * m + j], w, qc[i]);                    // Q[i][c] -= L[i][j] D[j] L[c][j]
+                });
+            });
+            static_for<0, m>([&](auto lc) {                                            // D^-1, then L' x = z from the last row up
+                constexpr int l = m - 1 - decltype(lc)::value;
+                double x1 = b1[l] * rinv[l], x2 = 0.0;
+                if constexpr (LTV) x2 = b2[l] * rinv[l];
+                static_for<l + 1, m>([&](auto qcx) {
+                    constexpr int q = decltype(qcx)::value;
+                    x1 = __builtin_fma(-Lr[q * m + l], b1[q], x1);
+                    if constexpr (LTV) x2 = __builtin_fma(-Lr[q * m + l], b2[q], x2);
+                });
+                b1[l] = x1;
+                if constexpr (LTV) b2[l] = x2;
+            });
+            static_for<0, m>([&](auto lc) {                                            // :107-108
+                constexpr int l = decltype(lc)::value;
+                Kc[l] = -b1[l];
+                k[l] = bcast_row<m>(Kc[l]);                                            // lane m solved for Q_u
+                if constexpr (LTV) wl[l] = b2[l];
+            });
+#pragma unroll
+            for (int l = 0; l < m; ++l) g = __builtin_fma(-Qu[l], k[l], g);            // :115
+            {
+                double sc = 0.0;                                                       // :116  (0.5 k' Q_uu)[c], then . k
+#pragma unroll
+                for (int l2 = 0; l2 < m; ++l2) sc = __builtin_fma(0.5 * k[l2], qo[l2], sc);
+                static_for<0, m>([&](auto lc) { constexpr int l = decltype(lc)::value; h = __builtin_fma(bcast_row<l>(sc), k[l], h); });
+            }
+#pragma unroll
+            for (int l = 0; l < m; ++l) KtQuu[l] = 0.0;
+            static_for<0, m>([&](auto lc) {                                            // (K' Q_uu)[i][l] = sum_l2 K[l2][i] Q_uu[l2][l]
+                constexpr int l = decltype(lc)::value;
+#pragma unroll
+                for (int l2 = 0; l2 < m; ++l2) fmac_row<l>(KtQuu[l], qo[l2], Kc[l2]);
+            });
+            double v1 = 0.0, v2 = 0.0, v3 = 0.0;                                       // :124
+#pragma unroll
+            for (int l = 0; l < m; ++l) v1 = __builtin_fma(KtQuu[l], k[l], v1);
+#pragma unroll
+            for (int l = 0; l < m; ++l) v2 = __builtin_fma(Kc[l], Qu[l], v2);
+#pragma unroll
+            for (int l = 0; l < m; ++l) v3 = __builtin_fma(Qux[l], k[l], v3);
+            vx = ((Qx + v1) + v2) + v3;
+        } else {
             double Quu[m * m], Quu_inv[m * m], Acol[n], Qx = 0.0;
 #pragma unroll
             for (int r = 0; r < n; ++r) Acol[r] = s[G::oAT + cc * LD + r];             // A[r][i]
@@ -854,8 +992,7 @@ __global__ void __launch_bounds__(64, RICCATI_GRP_WAVES) k_riccati_grp(const KAr
         for (int r = 0; r < n; ++r) Ri[r] = s[G::oT + cc * LD + r];                    // (A^T V_xx)[i][:]
 #pragma unroll
         for (int j = 0; j < n; ++j) Aw[j] = s[G::oAT + j * LD + cc];                   // own row of A_t again (its
-        double wl[LTV ? m : 1];                                                        // ltvlqr: (A'PB G^-1)[i][:]
-        if constexpr (LTV) {
+        if constexpr (LTV && !G::BIGM) {
             double apb[m];
 #pragma unroll
             for (int l = 0; l < m; ++l) apb[l] = 0.0;

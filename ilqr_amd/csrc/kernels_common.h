@@ -50,11 +50,15 @@ ILQR_DEFINE_SYSTEM(quadcopter, QUADCOPTER, !ILQR_QUAD_TRIG_LIB)   // library tri
 ILQR_DEFINE_SYSTEM(car, CAR, 1)
 ILQR_DEFINE_SYSTEM(double_integrator, DOUBLE_INTEGRATOR, 1)
 ILQR_DEFINE_SYSTEM(double_pendulum, DOUBLE_PENDULUM, 1)
+ILQR_DEFINE_SYSTEM(floating_base, FLOATING_BASE, 1)
 
 struct SysInfo { const char* name; int n, m, np; };
-constexpr int N_SYSTEMS = 7;
+constexpr int N_SYSTEMS = 8;
 const SysInfo SYSTEMS[N_SYSTEMS] = {{"pendulum", 2, 1, 3}, {"acrobot", 4, 1, 5}, {"cartpole", 4, 1, 4}, {"quadcopter", 12, 4, 8},
-                                    {"car", 4, 2, 1}, {"double_integrator", 2, 1, 1}, {"double_pendulum", 4, 2, 5}};
+                                    {"car", 4, 2, 1}, {"double_integrator", 2, 1, 1}, {"double_pendulum", 4, 2, 5}, {"floating_base", 12, 12, 17}};
+// One lane per problem holds Q_uu, its inverse and K in registers: up to 4 inputs.  Beyond (floating base, 12 inputs) only the
+// lane-group recursion (k_riccati_grp) exists, and the kernels below are not instantiated.
+template <class S> constexpr bool lane_recursion_ok = S::m <= 4;
 
 // ------------------------------------------------------------------------------------------------
 // kernel arguments

@@ -89,6 +89,13 @@ def symbolic_dynamics_double_pendulum():
     return _triple('double_pendulum')
 
 
+def symbolic_dynamics_floating_base():
+    """matlab/smooth-ilqr/symbolic_dynamics_floating_base.m (a rigid trunk driven by four feet's ground-reaction forces:
+    12 states [position, roll-pitch-yaw, linear velocity, world angular velocity], 12 inputs [F_1; F_2; F_3; F_4],
+    parameters [I_xx, I_yy, I_zz, m, g, foot_pos_1 (3), ..., foot_pos_4 (3)])."""
+    return _triple('floating_base')
+
+
 def system_of(*callables):
     """The common compiled system of the given dynamics callables; TypeError for anything else."""
     names = set()

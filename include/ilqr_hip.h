@@ -29,7 +29,7 @@ extern "C" {
 
 /* systems compiled into the library (sympy-generated __device__ dynamics, ilqr_amd/csrc/dynamics/) */
 enum { ILQR_SYS_PENDULUM = 0, ILQR_SYS_ACROBOT = 1, ILQR_SYS_CARTPOLE = 2, ILQR_SYS_QUADCOPTER = 3, ILQR_SYS_CAR = 4,
-       ILQR_SYS_DOUBLE_INTEGRATOR = 5, ILQR_SYS_DOUBLE_PENDULUM = 6 };
+       ILQR_SYS_DOUBLE_INTEGRATOR = 5, ILQR_SYS_DOUBLE_PENDULUM = 6, ILQR_SYS_FLOATING_BASE = 7 };
 
 /* per-problem exit reason of solve(): python/ilqr.py:170-207 */
 enum {

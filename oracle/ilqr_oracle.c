@@ -48,14 +48,15 @@
 #include "../ilqr_amd/csrc/dynamics/car.h"
 #include "../ilqr_amd/csrc/dynamics/double_integrator.h"
 #include "../ilqr_amd/csrc/dynamics/double_pendulum.h"
+#include "../ilqr_amd/csrc/dynamics/floating_base.h"
 
 #define MAXN 12
-#define MAXM 4
+#define MAXM 12
 
 typedef void (*dyn_fn)(const double*, const double*, const double, const double*, double*);
 typedef struct { int n, m, np; dyn_fn f, A, B; } oracle_system;
 
-#define N_SYSTEMS 7
+#define N_SYSTEMS 8
 static const oracle_system SYSTEMS[N_SYSTEMS] = {
     {ILQR_DYN_PENDULUM_N, ILQR_DYN_PENDULUM_M, ILQR_DYN_PENDULUM_NP, ilqr_dyn_pendulum_f, ilqr_dyn_pendulum_A, ilqr_dyn_pendulum_B},
     {ILQR_DYN_ACROBOT_N, ILQR_DYN_ACROBOT_M, ILQR_DYN_ACROBOT_NP, ilqr_dyn_acrobot_f, ilqr_dyn_acrobot_A, ilqr_dyn_acrobot_B},
@@ -64,6 +65,7 @@ static const oracle_system SYSTEMS[N_SYSTEMS] = {
     {ILQR_DYN_CAR_N, ILQR_DYN_CAR_M, ILQR_DYN_CAR_NP, ilqr_dyn_car_f, ilqr_dyn_car_A, ilqr_dyn_car_B},
     {ILQR_DYN_DOUBLE_INTEGRATOR_N, ILQR_DYN_DOUBLE_INTEGRATOR_M, ILQR_DYN_DOUBLE_INTEGRATOR_NP, ilqr_dyn_double_integrator_f, ilqr_dyn_double_integrator_A, ilqr_dyn_double_integrator_B},
     {ILQR_DYN_DOUBLE_PENDULUM_N, ILQR_DYN_DOUBLE_PENDULUM_M, ILQR_DYN_DOUBLE_PENDULUM_NP, ilqr_dyn_double_pendulum_f, ilqr_dyn_double_pendulum_A, ilqr_dyn_double_pendulum_B},
+    {ILQR_DYN_FLOATING_BASE_N, ILQR_DYN_FLOATING_BASE_M, ILQR_DYN_FLOATING_BASE_NP, ilqr_dyn_floating_base_f, ilqr_dyn_floating_base_A, ilqr_dyn_floating_base_B},
 };
 
 int oracle_system_dims(int sys, int* n, int* m, int* np)

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, 'libilqr_oracle.so')
 SYSTEM_IDS = {'pendulum': 0, 'acrobot': 1, 'cartpole': 2, 'quadcopter': 3, 'car': 4, 'double_integrator': 5,
-              'double_pendulum': 6}
+              'double_pendulum': 6, 'floating_base': 7}
 DEFAULT_OPTS = (0.95, 0.05, 1e-3, 0.1)   # ilqr.py:166-169
 
 _SO_FMA = os.path.join(_HERE, 'libilqr_oracle_fma.so')

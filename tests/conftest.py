@@ -41,9 +41,11 @@ def elem_err(a, b, floor_frac=1e-3):
 # the CPU oracle -- bit-identical dynamics, LU inverse like numpy -- is itself 4.6e-8 from numpy on this measure (numpy's
 # 12 x 12 products go through OpenBLAS dgemm, another summation order), the GPU (Cholesky-based inverse, fused products)
 # 1.7e-7; in both cases the difference sits in entries at the floor (|K| ~ 1e-10 where the hover symmetry makes the exact
-# value 0: absolute error 1e-9 on gains of size 7, 1.7e-10 norm-wise).
+# value 0: absolute error 1e-9 on gains of size 7, 1.7e-10 norm-wise).  Floating base (12 x 12 Q_uu = 1e-4 I + a rank-6
+# term, 100 steps): the same picture -- oracle vs numpy 2.6e-7, in entries that are exactly 0 by the stance's symmetry and
+# come out as +-3e-8 on gains of size 110 (3e-10 norm-wise), with opposite signs in the two.
 def elem_tol(system):
-    return 5e-7 if system == 'quadcopter' else 1e-8
+    return {'quadcopter': 5e-7, 'floating_base': 2e-6}.get(system, 1e-8)
 
 
 @pytest.fixture(scope='session')

@@ -12,7 +12,7 @@ import pytest
 
 from conftest import ROOT, elem_err, elem_tol, golden, rel_err
 
-SYSTEMS = ['pendulum', 'acrobot', 'cartpole', 'quadcopter', 'car', 'double_integrator', 'double_pendulum']
+SYSTEMS = ['pendulum', 'acrobot', 'cartpole', 'quadcopter', 'car', 'double_integrator', 'double_pendulum', 'floating_base']
 KAT_SYSTEMS = ['pendulum', 'acrobot', 'cartpole', 'quadcopter', 'car']     # systems with a MATLAB *-trajectory.mat
 TOL = 1e-8
 
@@ -52,7 +52,7 @@ def test_oracle_single_passes(oracle, system):
         assert rel_err(np.vstack([fu[::stride], fu[-1:]]), p['fwd%d_inputs' % i]) < 1e-12
 
 
-@pytest.mark.parametrize('system', ['pendulum', 'acrobot', 'quadcopter', 'car', 'double_integrator'])
+@pytest.mark.parametrize('system', ['pendulum', 'acrobot', 'quadcopter', 'car', 'double_integrator', 'floating_base'])
 def test_oracle_full_solve(oracle, system):
     g = golden(system + '_solve')
     r = oracle.solve(system, g['init'], g['target'], g['guess'], g['Qk'], g['Rk'], g['QT'], float(g['dt']), g['params'],

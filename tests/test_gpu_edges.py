@@ -130,10 +130,11 @@ def test_car_accepts_an_empty_parameter_vector(amd):
     assert f(np.zeros(4), np.zeros(2), 0.01, []).shape == (4, 1)
 
 
-@pytest.mark.parametrize('system', ['car', 'double_pendulum', 'quadcopter'])
+@pytest.mark.parametrize('system', ['car', 'double_pendulum', 'quadcopter', 'floating_base'])
 def test_nan_problem_with_several_inputs_ends_like_the_reference(amd, oracle, system):
     """m > 1: Q_uu of a diverged (NaN) trajectory is not positive definite, so the Cholesky fast path hands over to the
-    LU inverse with np.linalg.inv's rule (error on an exactly zero pivot only).  The problem then ends the way it does in
+    LU inverse with np.linalg.inv's rule (error on an exactly zero pivot only; 12 inputs: the factorisation across the lane
+    group carries the NaN through).  The problem then ends the way it does in
     the reference and for m = 1: every Armijo test is False -> 'low learning rate' after one iteration, not 'numerical'."""
     g = golden(system + '_batch')
     init, guess = g['init'].copy(), g['guess']
@@ -149,16 +150,20 @@ def test_nan_problem_with_several_inputs_ends_like_the_reference(amd, oracle, sy
     assert rel_err(out[0][keep], r['states'][keep]) < TOL and rel_err(out[3][keep], r['K'][keep]) < TOL
 
 
-@pytest.mark.parametrize('system', ['car', 'double_pendulum'])
+@pytest.mark.parametrize('system', ['car', 'double_pendulum', 'floating_base'])
 def test_indefinite_quu_is_inverted_like_numpy(amd, oracle, system):
     """an indefinite R_k makes Q_uu indefinite: np.linalg.inv (LU, partial pivoting) inverts it without complaint
-    (ilqr.py:106), and so must the backward pass -- same gains as the oracle's LU inverse, status 0, no exception"""
+    (ilqr.py:106), and so must the backward pass -- same gains as the oracle's LU inverse, status 0, no exception
+    (12 inputs: L D L' across the lane group, D with a negative entry)"""
     g = golden(system + '_passes')
     f, A, B = getattr(amd, 'symbolic_dynamics_' + system)()
     dt = float(g['dt'])
     Bl = oracle.dynamics(system, 'B', g['states0'][-2:-1], g['inputs0'][-1:], dt, g['params'])[0]
     BQB = Bl.T @ g['QT'] @ Bl
-    Rk = np.array([[-3.0, 0.4], [0.4, 0.5]]) * max(float(np.abs(g['Rk']).max()), 10.0 * float(np.abs(BQB).max()))
+    m = Bl.shape[1]
+    Rk = 0.5 * np.eye(m)
+    Rk[:2, :2] = [[-3.0, 0.4], [0.4, 0.5]]
+    Rk *= max(float(np.abs(g['Rk']).max()), 10.0 * float(np.abs(BQB).max()))
     ev = np.linalg.eigvalsh(Rk + BQB)                                      # Q_uu of the first step of the recursion
     assert ev[0] < 0 < ev[-1]
     s = amd.ilqr(g['init'], g['target'], g['guess'], dt, float(g['start']), float(g['end']), f, A, B, g['Qk'], Rk, g['QT'], g['params'], 1)

@@ -13,7 +13,7 @@ from conftest import elem_err, elem_tol, golden, rel_err
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-8
-SYSTEMS = ['pendulum', 'acrobot', 'cartpole', 'quadcopter', 'car', 'double_integrator', 'double_pendulum']
+SYSTEMS = ['pendulum', 'acrobot', 'cartpole', 'quadcopter', 'car', 'double_integrator', 'double_pendulum', 'floating_base']
 KAT_SYSTEMS = ['pendulum', 'acrobot', 'cartpole', 'quadcopter', 'car']     # systems with a MATLAB *-trajectory.mat
 
 
@@ -118,7 +118,7 @@ def check_solve(out, g, n_it_check=None):
     assert abs(cost - float(g['cost'])) <= TOL * abs(float(g['cost']))
 
 
-@pytest.mark.parametrize('system', ['pendulum', 'acrobot', 'quadcopter', 'car', 'double_integrator'])
+@pytest.mark.parametrize('system', ['pendulum', 'acrobot', 'quadcopter', 'car', 'double_integrator', 'floating_base'])
 def test_solve_example_config(amd, system):
     """full solve() of the reference's example configuration vs the reference's own output"""
     g = golden(system + '_solve')
@@ -211,13 +211,15 @@ def random_batch(system, B, N, seed):
     g = golden(system + '_batch')
     rng = np.random.default_rng(seed)
     n, m = g['init'].shape[1], g['guess'].shape[2]
-    init = g['init'][0] + rng.uniform(-0.2, 0.2, (B, n))
+    # (floating base: +-0.2 on every state -- attitude and rates included -- gives problems whose first iterations jump to
+    # costs of 1e4 and amplify rounding to 1e-4 between any two implementations; +-0.05 keeps them conditioned)
+    init = g['init'][0] + rng.uniform(-0.2, 0.2, (B, n)) * (0.25 if system == 'floating_base' else 1.0)
     guess = np.resize(g['guess'][0], (N, m))[None] + 0.05 * rng.standard_normal((B, N, m))
     return g, init, guess
 
 
 @pytest.mark.parametrize('system,B,N', [('pendulum', 130, 150), ('acrobot', 65, 200), ('cartpole', 64, 120), ('quadcopter', 5, 40),
-                                            ('car', 70, 100), ('double_pendulum', 66, 150)])
+                                            ('car', 70, 100), ('double_pendulum', 66, 150), ('floating_base', 7, 40)])
 def test_solve_vs_oracle_ragged_batch(amd, oracle, system, B, N):
     """batch sizes that are not multiples of the 64-problem tile; per-problem targets and parameters"""
     g, init, guess = random_batch(system, B, N, seed=11)
@@ -237,7 +239,8 @@ def test_solve_vs_oracle_ragged_batch(amd, oracle, system, B, N):
         check_solve((states[b], inputs[b], k[b], K[b], cost[b]), ref[b])
 
 
-@pytest.mark.parametrize('system,B,N,widths', [('acrobot', 9, 150, (1, 8, 64)), ('quadcopter', 11, 60, (1, 4, 8, 16, 32, 64))])
+@pytest.mark.parametrize('system,B,N,widths', [('acrobot', 9, 150, (1, 8, 64)), ('quadcopter', 11, 60, (1, 4, 8, 16, 32, 64)),
+                                               ('floating_base', 6, 50, (16, 32, 64))])
 def test_alpha_width_does_not_change_results(amd, system, B, N, widths):
     """the number of concurrently evaluated line-search trials is a scheduling choice: same accepted trial, same bits.
     For the quadcopter W >= 8 takes the LDS-staged rollout (one shared record per problem), W < 8 the per-lane loads."""
@@ -394,6 +397,28 @@ def test_ltvlqr_quadcopter_vs_oracle(amd, oracle):
     assert K.shape == (B, N, 4, 12)
     for b in range(B):
         assert rel_err(K[b], Ko[b]) < TOL
+
+
+def test_ltvlqr_floating_base_vs_oracle(amd, oracle):
+    """n = 12, m = 12: G = R + B'PB is factorised across the lanes of the group (one column per lane, no 12 x 12 inverse in
+    registers) and A'PB G^-1 comes out of the same solve; against the CPU oracle's explicit inverse (ltvlqr.py:23-27).
+    Also the 12-input backward pass is rejected on the one-lane schedules."""
+    g = golden('floating_base_solve')
+    rng = np.random.default_rng(6)
+    B, N = 7, 90
+    states = g['states'][None, :N + 1] + 1e-2 * rng.standard_normal((B, N + 1, 12))
+    inputs = g['inputs'][None, :N] + 1e-1 * rng.standard_normal((B, N, 12))
+    Qk, Rk, QT = 0.1 * np.eye(12), 0.01 * np.eye(12) + 0.002 * np.ones((12, 12)), 100 * np.eye(12)
+    _, A, Bf = amd.symbolic_dynamics_floating_base()
+    K = amd.ltvlqr(states, inputs, A, Bf, Qk, Rk, QT, float(g['dt']), g['params'])
+    Ko = oracle.ltvlqr_batched('floating_base', states, inputs, Qk, Rk, QT, float(g['dt']), g['params'])
+    assert K.shape == (B, N, 12, 12)
+    for b in range(B):
+        assert rel_err(K[b], Ko[b]) < TOL
+    with pytest.raises(amd.IlqrHipError, match='more than 4 inputs'):
+        amd.Workspace('floating_base', 50, 4, 0.005, riccati=1)
+    with pytest.raises(amd.IlqrHipError, match='tracking'):
+        amd.Workspace('floating_base', 50, 4, 0.005, tracking=1)
 
 
 def test_ltvlqr_group_recursion_on_a_small_system(amd):

@@ -9,8 +9,9 @@ to run without /root/reference (it is never run on the GPU box).
 Fixtures (all float64, reference numpy layout):
   dyn_<sys>.npz            random-point f/A/B of the lambdified callables (acrobot: the reference's own
                            symbolic_dynamics_acrobot(); pendulum: the reference expression with the
-                           sp.sp.sin typo of symbolic_dynamics.py:12 fixed; cartpole/quadcopter: the
-                           build's sympy re-derivation of the MATLAB specs, lambdified)
+                           sp.sp.sin typo of symbolic_dynamics.py:12 fixed; the other systems: the
+                           build's sympy re-derivation of the MATLAB specs, lambdified; the floating base has no example
+                           script in the reference, its configuration is synthetic -- see cfg_floating_base)
   mat_kat_<sys>.npz        one-step pairs x_i,u_i -> x_{i+1} from the reference's MATLAB .mat trajectories
   acrobot_csv.npz          the reference's committed acrobot_swingup_{states,inputs}.csv as arrays
   <sys>_solve.npz          full ilqr.solve() of the example config + per-iteration trace + Armijo ratios
@@ -181,8 +182,25 @@ def cfg_double_pendulum():   # example_double_pendulum.m:4-38 (horizon shortened
                 params=np.array([1, 1, 2, 1, 9.8]), n_iterations=50)
 
 
+def cfg_floating_base():   # no example script in the reference (symbolic_dynamics_floating_base.m only): a synthetic quadruped
+    # trunk -- 9 kg, feet on the ground under the corners, standing guess (every foot carries a quarter of the weight),
+    # asked to shift, rise and yaw within half a second.  gravity enters as [0; 0; g] (:70), hence g < 0.  The trunk starts
+    # at the origin (feet 0.3 below): row 0 of the reference's state trajectory is never written (ilqr.py:31-42), so with a
+    # non-zero initial state the first step's feedback acts on a spurious deviation and the search runs out after 3 iterations.
+    dt, t0, t1 = 0.005, 0, 0.5
+    N = np.arange(t0, t1, dt).shape[0]
+    mass, g = 9.0, -9.81
+    feet = [0.2, 0.15, -0.3, 0.2, -0.15, -0.3, -0.2, 0.15, -0.3, -0.2, -0.15, -0.3]
+    init = np.zeros(12)
+    target = np.zeros(12); target[:3] = [0.1, -0.05, 0.05]; target[3:6] = [0.0, 0.05, 0.2]
+    guess = np.zeros((N, 12)); guess[:, 2::3] = -mass * g / 4
+    return dict(dt=dt, start=t0, end=t1, init=init, target=target, guess=guess, Qk=np.zeros((12, 12)), Rk=1e-4 * np.eye(12),
+                QT=100 * np.eye(12), params=np.array([0.07, 0.26, 0.242, mass, g] + feet), n_iterations=30)
+
+
 CONFIG = {'pendulum': cfg_pendulum, 'acrobot': cfg_acrobot, 'cartpole': cfg_cartpole, 'quadcopter': cfg_quadcopter,
-          'car': cfg_car, 'double_integrator': cfg_double_integrator, 'double_pendulum': cfg_double_pendulum}
+          'car': cfg_car, 'double_integrator': cfg_double_integrator, 'double_pendulum': cfg_double_pendulum,
+          'floating_base': cfg_floating_base}
 
 
 def make(c, fab, cls=TracedIlqr, **over):
@@ -212,7 +230,7 @@ def gen_dynamics(name, fab):
     rng = np.random.default_rng(100 + models.SYSTEM_IDS[name])
     cnt = 256
     x = rng.uniform(-3.0, 3.0, (cnt, n))
-    if name == 'quadcopter':
+    if name in ('quadcopter', 'floating_base'):
         x[:, 4] = rng.uniform(-1.2, 1.2, cnt)      # pitch away from the tan/sec singularity
     u = rng.uniform(-2.0, 2.0, (cnt, m))
     x[0] = 0.0; u[0] = 0.0
@@ -280,12 +298,13 @@ def gen_batch(name, fab, B=8):
     n = len(c['init'])
     m = c['guess'].shape[1]
     short = {'pendulum': 1.0, 'acrobot': 0.4, 'cartpole': 1.5, 'quadcopter': 0.5, 'car': 1.0, 'double_integrator': 1.0,
-             'double_pendulum': 0.4}[name]
+             'double_pendulum': 0.4, 'floating_base': 0.25}[name]
     rng = np.random.default_rng(7 + models.SYSTEM_IDS[name])
     N = np.arange(c['start'], short, c['dt']).shape[0]
-    inits = np.asarray(c['init'], float) + rng.uniform(-0.2, 0.2, (B, n))
+    # (floating base: larger deviations end some of the 8 searches early, and the fixture stacks equal iteration counts)
+    inits = np.asarray(c['init'], float) + rng.uniform(-0.2, 0.2, (B, n)) * (0.25 if name == 'floating_base' else 1.0)
     scale = {'pendulum': 0.1, 'acrobot': 0.5, 'cartpole': 0.05, 'quadcopter': 0.02, 'car': 0.2, 'double_integrator': 0.2,
-             'double_pendulum': 0.2}[name]
+             'double_pendulum': 0.2, 'floating_base': 1.0}[name]
     guesses = c['guess'][:N][None] + scale * rng.standard_normal((B, N, m))
     res = []
     for b in range(B):
@@ -356,13 +375,15 @@ def main():
         return
     fabs = {}
     for name in models.BUILDERS:
-        fabs[name] = lambdified(name)
+        if not only or name in only or (name in ('acrobot', 'pendulum') and (only == {'tracking'} or 'pendulum' in only)):
+            fabs[name] = lambdified(name)
     print('writing fixtures to', OUT)
     if only == {'tracking'}:          # only the tracking simulations, from the trajectories already in tests/golden
         pl = np.load(os.path.join(OUT, 'pendulum_ltvlqr.npz'))
         gen_ltvlqr(fabs, dict(states=pl['states'], inputs=pl['inputs']))
         return
-    gen_mat_kats()
+    if not only:
+        gen_mat_kats()
     solves = {}
     for name in models.BUILDERS:
         if only and name not in only:
