@@ -8,11 +8,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 3 --warmup 1 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-extra > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU" "GRBM_GUI_ACTIVE"; do
   n=$(echo $pass | cut -d" " -f1)
   timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$n -- python3 $R/tools/pmc_probe.py > $OUT/pmc_$n.log 2>&1
 done
-cd $R && timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
+cd $R && timeout -k 10 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 tools/summarize_pmc.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_summary.json
 echo done
