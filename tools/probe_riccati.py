@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the backward pass alone (linearize + Riccati, split schedule) on the C5 quadcopter shard (development aid).
-usage: python tools/probe_riccati.py [scale] [system]"""
+usage: python tools/probe_riccati.py [scale] [system] [riccati]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,8 @@ sysname = sys.argv[2] if len(sys.argv) > 2 else 'quadcopter'
 g = np.load(G + '/%s_solve.npz' % sysname)
 B = int(32768 * scale)
 N, n = g['guess'].shape[0], g['init'].shape[0]
-ws = ilqr_amd.Workspace(sysname, N, B, float(g['dt']), n_iterations=10, pipeline=2, riccati=2)
+ric = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+ws = ilqr_amd.Workspace(sysname, N, B, float(g['dt']), n_iterations=10, pipeline=2, riccati=ric, overlap=1)
 ws.set_weights(g['Qk'], g['Rk'], g['QT']); ws.upload(_lib.F_PARAMS, g['params']); ws.upload(_lib.F_TARGET, g['target'])
 ws.upload(_lib.F_INIT, np.tile(g['init'], (B, 1))); ws.upload(_lib.F_GUESS, np.broadcast_to(g['guess'], (B,) + g['guess'].shape).copy())
 ws.rollout(); ws.sync()
