@@ -21,6 +21,8 @@ source with ``ast`` and re-emits the same expression tree in C:
   ``if (ILQR_DYN_TRIG_BIG(a0) || ...) { ILQR_DYN_SINCOS_SLOW(...) }`` lets the device
   patch huge / non-finite arguments with the general ocml routines (never taken
   on sane trajectories; the oracle defines TRIG_BIG as 0),
+* in ``f_sc`` divisors that are a state- and input-free multiple of another divisor share its reciprocal
+  (``_proportional_divisors``)
 * ``a / d`` becomes ``ILQR_DYN_DIV(a, d, rdK)`` with one hoisted ``rdK = ILQR_DYN_RCP(d)``
   per distinct non-constant divisor: the oracle defines DIV as the plain ``a / d``
   (so it stays bit-identical to numpy); the device shares the reciprocal among the
@@ -80,6 +82,7 @@ class _Emitter:
         self.tan_defs = []   # (index, argument) of tan calls
         self.rcp = {}        # C text of a divisor -> index of its hoisted reciprocal
         self.rcp_defs = []
+        self.rcp_ast = {}    # index -> (C text, python ast) of the divisor
 
     def elements(self):
         call = self.ret
@@ -139,6 +142,7 @@ class _Emitter:
         d = self.expr(den)
         if d not in self.rcp:
             self.rcp[d] = len(self.rcp)
+            self.rcp_ast[self.rcp[d]] = (d, den)
             self.rcp_defs.append('const double rd%d = ILQR_DYN_RCP(%s); (void)rd%d;' % (self.rcp[d], d, self.rcp[d]))
         return 'ILQR_DYN_DIV(%s, %s, rd%d)' % (n, d, self.rcp[d])
 
@@ -271,15 +275,80 @@ def _function_f_sc(model, em, els, sums):
             lines.append('    const double tn%d = ILQR_DYN_TAN_SC(%s, sn%d, cs%d);' % (i, arg, pair[arg], pair[arg]))
         else:
             lines.append('    const double tn%d = ILQR_DYN_TAN(%s);' % (i, arg))
-    for d in em.rcp_defs:
-        lines.append('    ' + d)
+    # Divisors that differ by a factor free of states and inputs (acrobot: D, L_2 D, L_2^2 m_2 D) share ONE reciprocal
+    # and one evaluation here: d_i = c_i * d_base, 1/d_i = (1/c_i) * (1/d_base), with c_i and 1/c_i invariant along a rollout
+    # (the compiler hoists them out of the time loop).  The quotient keeps its residual correction against d_i, so it
+    # stays within an ulp of a / d_i; d_i itself may differ from the reference's expression in the last bit, which
+    # reaches the state scaled by dt (f only -- the plain f above and the Jacobians keep every divisor as lambdify wrote it).
+    shared = _proportional_divisors(em)
+    subst = {}
+    for i in sorted(em.rcp_ast, key=lambda q: (q in shared, q)):          # the base before the divisors derived from it
+        text = em.rcp_ast[i][0]
+        if i in shared:
+            base, ratio_c, inv_c = shared[i]
+            lines.append('    const double dv%d = %s * dv%d;' % (i, ratio_c, base))
+            lines.append('    const double rd%d = %s * rd%d; (void)rd%d;' % (i, inv_c, base, i))
+            subst[i] = text
+        elif any(b == i for b, _, _ in shared.values()):
+            lines.append('    const double dv%d = %s;' % (i, text))
+            lines.append('    const double rd%d = ILQR_DYN_RCP(dv%d); (void)rd%d;' % (i, i, i))
+            subst[i] = text
+        else:
+            lines.append('    ' + em.rcp_defs[i])
     k = 0
     for row in els:
         for e in row:
+            for i, text in subst.items():
+                e = e.replace('%s, rd%d)' % (text, i), 'dv%d, rd%d)' % (i, i))
             lines.append('    out[%d] = %s;' % (k, e))
             k += 1
     lines.append('}')
     return lines
+
+
+def _proportional_divisors(em):
+    """{index: (base index, C text of d_i / d_base, C text of d_base / d_i)} for the divisors of one function that are a
+    state- and input-free multiple of another one (the base: the divisor most others are multiples of, then the shortest)."""
+    if len(em.rcp_ast) < 2:
+        return {}
+    loc = {name: sp.Symbol(name, real=True) for name in em.names}
+    free = {sp.Symbol(name, real=True) for name, c in em.names.items() if c.startswith('p[') or c == 'dt'}
+    exprs = {i: sp.sympify(ast.unparse(node), locals=loc) for i, (_, node) in em.rcp_ast.items()}
+    best = {}
+    for b in sorted(exprs, key=lambda i: (len(em.rcp_ast[i][0]), i)):
+        found = {}
+        if not (exprs[b].free_symbols - free):
+            continue                                        # a divisor without states is no base (nothing to share per step)
+        for i in exprs:
+            if i == b:
+                continue
+            ratio = sp.simplify(exprs[i] / exprs[b])
+            if ratio.free_symbols <= free and ratio != 0:
+                found[i] = ratio
+        if len(found) > len(best):
+            best = {i: (b, r) for i, r in found.items()}
+    def plain(node):
+        """C text of a parameter-only expression: plain IEEE operations (evaluated once per rollout, not per step)"""
+        if isinstance(node, ast.BinOp):
+            if isinstance(node.op, ast.Pow):
+                assert isinstance(node.right, ast.Constant) and isinstance(node.right.value, int) and 1 <= node.right.value <= 4, ast.dump(node)
+                return '(' + ' * '.join([plain(node.left)] * node.right.value) + ')'
+            op = {ast.Add: '+', ast.Sub: '-', ast.Mult: '*', ast.Div: '/'}[type(node.op)]
+            return '(%s %s %s)' % (plain(node.left), op, plain(node.right))
+        if isinstance(node, ast.UnaryOp) and isinstance(node.op, ast.USub):
+            return '(-%s)' % plain(node.operand)
+        if isinstance(node, ast.Constant):
+            return repr(float(node.value))
+        if isinstance(node, ast.Name):
+            return em.names[node.id]
+        raise NotImplementedError(ast.dump(node))
+
+    out = {}
+    for i, (b, ratio) in best.items():
+        num, den = sp.fraction(sp.together(ratio))
+        c = lambda e: plain(ast.parse(sp.pycode(e), mode='eval').body)
+        out[i] = (b, '(%s / %s)' % (c(num), c(den)) if den != 1 else c(num), '(%s / %s)' % (c(den), c(num)))
+    return out
 
 
 def generate(name):
