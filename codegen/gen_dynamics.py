@@ -262,8 +262,11 @@ def _function_f_sc(model, em, els, sums):
             lines.append('    double sn%d, cs%d; ILQR_DYN_SINCOS(%s, sn%d, cs%d); (void)sn%d; (void)cs%d;' % (i, i, arg, i, i, i, i))
             direct.append((arg, i))
     for i, (a, ia, b, ib) in sorted(sums.items()):
-        lines.append('    double sn%d, cs%d; ILQR_DYN_SINCOS_SUM(%s, %s, sn%d, cs%d, sn%d, cs%d, sn%d, cs%d); (void)sn%d; (void)cs%d;'
-                     % (i, i, a, b, ia, ia, ib, ib, i, i, i, i))
+        # both operands' pairs carried by the caller: ILQR_DYN_SINCOS_SUM_SC (the includer may drop the correction for the
+        # rounding of a + b there: it is smaller than the carried pairs' own error)
+        mac = 'ILQR_DYN_SINCOS_SUM_SC' if ia in slot and ib in slot else 'ILQR_DYN_SINCOS_SUM'
+        lines.append('    double sn%d, cs%d; %s(%s, %s, sn%d, cs%d, sn%d, cs%d, sn%d, cs%d); (void)sn%d; (void)cs%d;'
+                     % (i, i, mac, a, b, ia, ia, ib, ib, i, i, i, i))
     if direct:
         lines.append('    if (%s) {' % ' || '.join('ILQR_DYN_TRIG_BIG(%s)' % a for a, i in direct))
         for a, i in direct:
@@ -362,7 +365,7 @@ def generate(name):
                  ' * Reference: /root/reference/python/symbolic_dynamics.py:23-25,88-90 (lambdify call sites).\n'
                  ' * Row-major: f out[n], A out[n*n] (A[i][j] = out[i*n+j]), B out[n*m].\n'
                  ' * The includer defines ILQR_DYN_FN, ILQR_DYN_CONST, ILQR_DYN_SINCOS(x, s, c), ILQR_DYN_SINCOS_SLOW(x, s, c),\n'
-                 ' * ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c), ILQR_DYN_TRIG_BIG(x), ILQR_DYN_TAN(x), ILQR_DYN_TAN_SC(x, s, c), ILQR_DYN_RCP(d), ILQR_DYN_DIV(a, d, rd), ILQR_DYN_F_PROLOGUE and must compile\n'
+                 ' * ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c), ILQR_DYN_SINCOS_SUM_SC(same), ILQR_DYN_TRIG_BIG(x), ILQR_DYN_TAN(x), ILQR_DYN_TAN_SC(x, s, c), ILQR_DYN_RCP(d), ILQR_DYN_DIV(a, d, rd), ILQR_DYN_F_PROLOGUE and must compile\n'
                  ' * with -ffp-contract=off. */'
                  % (name, name))
     parts.append('#ifndef ILQR_DYN_%s_H\n#define ILQR_DYN_%s_H' % (up, up))

@@ -93,6 +93,15 @@ __device__ __forceinline__ void ilqr_sincos_sum(const double a, const double b, 
     c_out = __builtin_fma(S, e, C);
 }
 
+// the same from pairs that are themselves carried along a rollout (TrigCarry): plain angle addition, i.e. sin and cos of
+// the exact sum a + b rather than of its rounding -- the difference, |e| <= ulp(a + b) / 2, is below those pairs' own error
+__device__ __forceinline__ void ilqr_sincos_sum_carried(const double sa, const double ca, const double sb, const double cb,
+                                                        double& s_out, double& c_out)
+{
+    s_out = __builtin_fma(sa, cb, ca * sb);
+    c_out = __builtin_fma(ca, cb, -(sa * sb));
+}
+
 // 1/d for the shared-reciprocal division below: hardware estimate + ILQR_RCP_NEWTON Newton steps.  The reciprocal is
 // only ever used by ilqr_div_shared, whose residual correction is itself a Newton step on the quotient (relative error
 // of the result = the reciprocal's, squared): ONE step on the estimate is enough for a quotient that equals the IEEE

@@ -43,6 +43,17 @@
 #define ILQR_DYN_SINCOS(x, s, c) ilqr_sincos_fast((x), (s), (c))
 #define ILQR_DYN_SINCOS_SLOW(x, s, c) do { const ilqr_sc sc_ = ilqr_sincos_slow(x); (s) = sc_.sinv; (c) = sc_.cosv; } while (0)
 #define ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c) ilqr_sincos_sum((a), (b), (sa), (ca), (sb), (cb), (s), (c))
+// in f_sc, where both pairs are carried along the rollout (TrigCarry: a few ulp of random walk between re-seeds), the
+// correction for the rounding of a + b (|e| <= ulp(a + b) / 2, below the pairs' own error) is dropped: 4 instead of 12
+// instructions.  ILQR_SUM_SC_EXACT = 1 keeps it.
+#ifndef ILQR_SUM_SC_EXACT
+#define ILQR_SUM_SC_EXACT 0
+#endif
+#if ILQR_SUM_SC_EXACT
+#define ILQR_DYN_SINCOS_SUM_SC(a, b, sa, ca, sb, cb, s, c) ilqr_sincos_sum((a), (b), (sa), (ca), (sb), (cb), (s), (c))
+#else
+#define ILQR_DYN_SINCOS_SUM_SC(a, b, sa, ca, sb, cb, s, c) ilqr_sincos_sum_carried((sa), (ca), (sb), (cb), (s), (c))
+#endif
 // ordered compare: a NaN angle is NOT "big" -- the fast path turns NaN into NaN just as well, and a diverged trial of the
 // line search (NaN state for the rest of its horizon) would otherwise drag its whole wave through the library path at
 // every step (131 072 cartpoles: 221 -> 209 ms per solve).  Inf counts as big (one step later it is NaN).
@@ -83,10 +94,12 @@
 #if ILQR_QUAD_TRIG_LIB
 #undef ILQR_DYN_SINCOS
 #undef ILQR_DYN_SINCOS_SUM
+#undef ILQR_DYN_SINCOS_SUM_SC
 #undef ILQR_DYN_TRIG_BIG
 #undef ILQR_DYN_TAN_SC
 #define ILQR_DYN_SINCOS(x, s, c) do { (s) = sin(x); (c) = cos(x); } while (0)
 #define ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c) do { (s) = sin((a) + (b)); (c) = cos((a) + (b)); } while (0)
+#define ILQR_DYN_SINCOS_SUM_SC(a, b, sa, ca, sb, cb, s, c) ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c)
 #define ILQR_DYN_TRIG_BIG(x) 0
 #define ILQR_DYN_TAN_SC(x, s, c) tan(x)
 #endif

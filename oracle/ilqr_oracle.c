@@ -36,6 +36,7 @@
 #define ILQR_DYN_F_PROLOGUE              /* the reference: every operation rounded separately */
 #define ILQR_DYN_TAN_SC(x, s, c) tan(x)   /* the reference: numpy tan */
 #define ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c) do { (s) = sin((a) + (b)); (c) = cos((a) + (b)); } while (0)   /* the reference: numpy sin/cos of the rounded sum */
+#define ILQR_DYN_SINCOS_SUM_SC(a, b, sa, ca, sb, cb, s, c) ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c)   /* (f_sc is not used here) */
 #define ILQR_DYN_TRIG_BIG(x) 0
 #define ILQR_DYN_TAN(x) tan(x)
 /* plain IEEE division, as numpy does; the hoisted reciprocal is a device-side device and unused here */
