@@ -659,10 +659,16 @@ int run_sharded(const ilqr_desc* d, F&& fn)
         sd.n_devices = 1;
         sd.batch = cnt;
         sd.device = d->device_wrap ? (((d->device + r) % ndev) + ndev) % ndev : d->device + r;
-        threads.emplace_back([&, r, lo, sd] {
-            rcs[r] = fn(sd, lo);
-            if (rcs[r]) errs[r] = g_err;                 // g_err is per thread: hand the message to the caller's
-        });
+        try {
+            threads.emplace_back([&, r, lo, sd] {
+                rcs[r] = fn(sd, lo);
+                if (rcs[r]) errs[r] = g_err;             // g_err is per thread: hand the message to the caller's
+            });
+        } catch (const std::exception& e) {              // no thread to be had: nothing may leave this function as a C++ exception
+            rcs[r] = -1;
+            errs[r] = std::string("could not start the shard's host thread: ") + e.what();
+            break;
+        }
     }
     for (auto& t : threads) t.join();
     for (int r = 0; r < G; ++r)

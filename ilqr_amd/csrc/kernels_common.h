@@ -172,8 +172,9 @@ struct TrigCarry {
                 const double sdt = (d * z) * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S4, S3), S2), S1);   // sin d - d
                 const double cm1 = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C4, C3), C2), C1);         // cos d - 1
                 const double s = sc[2 * k], c = sc[2 * k + 1];
-                sc[2 * k] = s + __builtin_fma(c, d, __builtin_fma(c, sdt, s * cm1));
-                sc[2 * k + 1] = c + __builtin_fma(-s, d, __builtin_fma(-s, sdt, c * cm1));
+                const double sd = d + sdt;                                             // sin d (its rounding: 2^-53 |d| < 1e-17)
+                sc[2 * k] = s + __builtin_fma(c, sd, s * cm1);
+                sc[2 * k + 1] = c + __builtin_fma(-s, sd, c * cm1);
             }
             if (!ok) seed(xn);
         }
