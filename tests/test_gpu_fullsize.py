@@ -289,3 +289,29 @@ def test_widening_round_schedule_changes_nothing(amd, system, B, N):
         assert np.array_equal(a, b, equal_nan=True)
     if system == 'acrobot':                                  # some searches went through every round (none accepted)
         assert (outs[0][3][:, :, 4] == -1).any()
+
+
+def test_floating_base_16384(amd, oracle):
+    """SURVEY 8(f) row 3 at the bench's size: 16 384 floating-base problems (n = 12, m = 12: Q_uu factorised across the lane
+    group), per-problem targets and perturbed initial states (the state[0] quirk makes those searches harder), N = 100"""
+    from ilqr_amd import _lib
+    g = golden('floating_base_solve')
+    B = 16384
+    N = g['guess'].shape[0]
+    rng = np.random.default_rng(9)
+    target = np.tile(g['target'], (B, 1))
+    target[:, :6] += rng.uniform(-0.05, 0.05, (B, 6))
+    init = np.zeros((B, 12))
+    init[1:] = rng.uniform(-0.02, 0.02, (B - 1, 12))                       # problem 0 is the fixture's example
+    target[0] = g['target']
+    guess = np.ascontiguousarray(np.broadcast_to(g['guess'][None], (B, N, 12)))
+    init[9000], target[9000] = init[11], target[11]
+    ws = solve_ws(amd, 'floating_base', g, init, guess, target, 10, target_batched=True)
+    assert ws.info()['pipeline'] == 'split' and min(ws.info()['ls_widths']) >= 16
+    sample = np.array([0, 11, 64, 9000, 16383])
+    trace, status, iters, cost = check_properties(amd, ws, 'floating_base', g, init, sample)
+    assert cost[11] == cost[9000] and np.array_equal(trace[11], trace[9000], equal_nan=True)
+    assert int(iters[0]) == int(g['iters']) and int(status[0]) == int(g['status'])           # the reference's own solve
+    assert np.array_equal(trace[0, :int(g['iters']), 4], g['trace'][:, 4]) and abs(cost[0] - float(g['cost'])) <= TOL * float(g['cost'])
+    assert rel_err(ws.download(_lib.F_KFB)[0], g['K']) < TOL
+    compare_sample_with_oracle(oracle, 'floating_base', g, init, guess, target, ws, [0, 64, 16383], 10)
