@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(64) k_rollout(const KArgs a)
     int next_seed = a.ck;
     auto one_step = [&](const int t, const double (&u)[m]) {
         double xn[n];
-        cost = cost + input_cost<m>(u, Rk);
+        cost = cost + stage_input_cost<m>(a, u, Rk);
         if constexpr (S::n_ang > 0) {
             S::f_sc(x, u, a.dt, p, trig.sc, xn);
             const bool reseed = t + 1 == next_seed;
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(64) k_cost(const KArgs a)
         for (int t = 0; t < a.N; ++t) {
             double u[m];
             load_col<m>(Up + (size_t)t * m * TILE, u);
-            cost = cost + input_cost<m>(u, Rk);
+            cost = cost + stage_input_cost<m>(a, u, Rk);
         }
     }
     load_col<n>(Xp + (size_t)a.N * n * TILE, x);
@@ -241,7 +241,7 @@ __device__ __forceinline__ double closed_loop_range(const KArgs& a, const double
             load_col<m>(UDp + (size_t)tn * m * TILE, udn);
             cost = cost + tracking_stage_cost<n, m>(x, u, xd, ud, Qk, Rk);         // ilqr_mpc.m:207-210
         } else {
-            cost = cost + input_cost<m>(u, Rk);
+            cost = cost + stage_input_cost<m>(a, u, Rk);
         }
         if constexpr (S::n_ang > 0) {
             S::f_sc(x, u, a.dt, p, trig.sc, xn);                                   // :151
@@ -345,6 +345,9 @@ __device__ __forceinline__ double closed_loop_staged(const KArgs& a, double* sw,
     __builtin_amdgcn_wave_barrier();
     double cost = 0.0;
     int next_ck = CKPT ? a.ck : 0;
+    TrigCarry<S> trig;                                                                 // as in closed_loop_range: same pairs, same bits
+    trig.seed(x);
+    int next_seed = a.ck;
     for (int t = 0; t < a.N; ++t) {
         fetch(t + 1 < a.N ? t + 1 : t);                                                // next record, in flight during this step
         const double* rec = sw + (t & 1) * (G * RECP) + grp * RECP;
@@ -369,8 +372,15 @@ __device__ __forceinline__ double closed_loop_staged(const KArgs& a, double* sw,
             for (int i = 0; i < n; ++i) fb = __builtin_fma(rec[T::oK + j * n + i], dx[i], fb);
             u[j] = (rec[T::oU + j] + fb) + ff;                                         // :148
         }
-        cost = cost + input_cost<m>(u, Rk);
-        S::f(x, u, a.dt, p, xn);                                                       // :151
+        cost = cost + stage_input_cost<m>(a, u, Rk);
+        if constexpr (S::n_ang > 0) {
+            S::f_sc(x, u, a.dt, p, trig.sc, xn);                                       // :151
+            const bool reseed = t + 1 == next_seed;
+            if (reseed) next_seed += a.ck;
+            trig.advance(x, xn, reseed);
+        } else {
+            S::f(x, u, a.dt, p, xn);                                                   // :151
+        }
 #pragma unroll
         for (int i = 0; i < n; ++i) x[i] = xn[i];
         __builtin_amdgcn_wave_barrier();                                               // reads of this parity's other buffer are done
