@@ -13,6 +13,8 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ
   n=$(echo $pass | cut -d" " -f1)
   timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$n -- python3 $R/tools/pmc_probe.py > $OUT/pmc_$n.log 2>&1
 done
-cd $R && timeout -k 10 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-python3 tools/summarize_pmc.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_summary.json
+# the traffic figures first (bench.py reports roofline.traffic from profiles/pmc_traffic.json when its source hash is the tree's)
+cd $R && python3 tools/summarize_pmc.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_summary.json
+cp $OUT/pmc_traffic.json $R/profiles/pmc_traffic.json
+timeout -k 10 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo done
