@@ -248,7 +248,11 @@ def make_workspace(cfg, B, device, args, want_trace=True):
         W = args.alphas if args.alphas else cfg['W']
         ws = ilqr_amd.Workspace(cfg['system'], cfg['N'], B, cfg['dt'], want_trace=want_trace, n_iterations=cfg['n_iterations'],
                                 n_alpha_parallel=W, device=device, n_streams=args.streams, riccati=args.riccati,
-                                target_batched=np.ndim(cfg['target']) == 2)
+                                target_batched=np.ndim(cfg['target']) == 2,
+                                # ranks sharing ONE GPU (--device-wrap, a rehearsal on a one-GPU box): the two-stream overlap
+                                # of accept and recursion is switched off -- with a second process on the same GPU its
+                                # cross-stream waits were seen to stall for good in about one run in five
+                                overlap=1 if getattr(args, 'device_wrap', False) else 0)
         ws.set_weights(cfg['Qk'], cfg['Rk'], cfg['QT'])
         ws.upload(_lib.F_INIT, cfg['init'])
         ws.upload(_lib.F_TARGET, cfg['target'])

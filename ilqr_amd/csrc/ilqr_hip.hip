@@ -949,6 +949,8 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
         // queues -- and the recursion is the critical path of the pair.
         int prio_least = 0, prio_greatest = 0;
         WSCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        const char* pe = getenv("ILQR_PIPE_PRIORITY");                      // development aid: 0 = a plain second stream
+        if (pe && atoi(pe) == 0) prio_greatest = prio_least;
         WSCHK(hipStreamCreateWithPriority(&ws->pipe_stream, hipStreamDefault, prio_greatest));
         for (int c = 0; c < OVERLAP_CHUNKS; ++c) WSCHK(hipEventCreateWithFlags(&ws->pipe_ev[c], hipEventDisableTiming));
         WSCHK(hipEventCreateWithFlags(&ws->pipe_done, hipEventDisableTiming));

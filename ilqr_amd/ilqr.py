@@ -17,7 +17,7 @@ from .symbolic_dynamics import system_of
 class ilqr:
     def __init__(self, init_state, target_state, initial_guess, dt, start_time, end_time, f_disc, A, B, Q_k, R_k, Q_T,
                  parameters, n_iterations, device=0, n_alpha_parallel=0, verbose=None, zero_first_state=True, pipeline=0, n_streams=0,
-                 n_devices=1):
+                 n_devices=1, overlap=0):
         self.init_state_ = init_state
         self.target_state_ = target_state
         self.inputs_ = initial_guess
@@ -53,6 +53,9 @@ class ilqr:
         # GPUs the batch is split over by problem index (device, device + 1, ...; 0 = every visible GPU): one host
         # thread per GPU inside the library, no exchange between them -- the problems are independent
         self.n_devices_ = n_devices
+        # 0 auto | 1 off | 2 on: accept step of iteration i alongside the recursion of iteration i + 1 on two HIP streams (small
+        # batches of 4-state systems).  Pass 1 when OTHER PROCESSES use the same GPU.  Same results.
+        self.overlap_ = overlap
         self.verbose_ = (not self.batched_) if verbose is None else verbose
 
         n, m, npar = _lib.system_dims(self.system_)
@@ -115,7 +118,7 @@ class ilqr:
         return _lib.make_desc(self.system_, self.n_timesteps_, self.batch_, self.dt_, n_iterations=n_iterations,
                               n_alpha_parallel=self.n_alpha_parallel_, zero_first_state=self.zero_first_state_,
                               device=self.device_, target_batched=tb, params_batched=pb, pipeline=self.pipeline_, n_streams=self.n_streams_,
-                              n_devices=n_dev)
+                              n_devices=n_dev, overlap=self.overlap_)
 
     # ------------------------------------------------------------------ ilqr.py:30-47
     def rollout(self):
