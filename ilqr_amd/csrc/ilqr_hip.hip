@@ -97,8 +97,9 @@
 #undef ILQR_DYN_SINCOS_SUM_SC
 #undef ILQR_DYN_TRIG_BIG
 #undef ILQR_DYN_TAN_SC
-#define ILQR_DYN_SINCOS(x, s, c) do { (s) = sin(x); (c) = cos(x); } while (0)
-#define ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c) do { (s) = sin((a) + (b)); (c) = cos((a) + (b)); } while (0)
+// (the library's sincos: one argument reduction for the pair, the same two kernels -- the same bits as sin() and cos())
+#define ILQR_DYN_SINCOS(x, s, c) do { double s_, c_; sincos((x), &s_, &c_); (s) = s_; (c) = c_; } while (0)
+#define ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c) do { double s_, c_; sincos((a) + (b), &s_, &c_); (s) = s_; (c) = c_; } while (0)
 #define ILQR_DYN_SINCOS_SUM_SC(a, b, sa, ca, sb, cb, s, c) ILQR_DYN_SINCOS_SUM(a, b, sa, ca, sb, cb, s, c)
 #define ILQR_DYN_TRIG_BIG(x) 0
 #define ILQR_DYN_TAN_SC(x, s, c) tan(x)
