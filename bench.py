@@ -250,9 +250,10 @@ def make_workspace(cfg, B, device, args, want_trace=True):
                                 n_alpha_parallel=W, device=device, n_streams=args.streams, riccati=args.riccati,
                                 target_batched=np.ndim(cfg['target']) == 2,
                                 # ranks sharing ONE GPU (--device-wrap, a rehearsal on a one-GPU box): the two-stream overlap
-                                # of accept and recursion is switched off -- with a second process on the same GPU its
-                                # cross-stream waits were seen to stall for good in about one run in five
-                                overlap=1 if getattr(args, 'device_wrap', False) else 0)
+                                # of accept and recursion is switched off -- with a second process on the same GPU a solve
+                                # stalled for good in 2 of 41 rehearsals, in none of 42 without it
+                                overlap=args.overlap if getattr(args, 'overlap', None) is not None
+                                else (1 if getattr(args, 'device_wrap', False) else 0))
         ws.set_weights(cfg['Qk'], cfg['Rk'], cfg['QT'])
         ws.upload(_lib.F_INIT, cfg['init'])
         ws.upload(_lib.F_TARGET, cfg['target'])
@@ -398,6 +399,8 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the extra_configs block (the other BASELINE configurations)')
     ap.add_argument('--streams', type=int, default=0, help='independent sub-batches of solve(), one HIP stream each (0 = library default)')
+    ap.add_argument('--overlap', type=int, default=None, choices=(0, 1, 2), help='accept / recursion overlap: 0 auto, 1 off, 2 on '
+                    '(default: auto, off with --device-wrap)')
     ap.add_argument('--riccati', type=int, default=0, help='backward recursion mapping: 0 auto, 1 lane per problem, 2 lane group')
     ap.add_argument('--force-dist', action='store_true', help='take the torch.distributed (RCCL) path even with one rank')
     ap.add_argument('--backend', default='nccl', choices=('nccl', 'gloo'), help='torch.distributed backend: nccl (= RCCL over xGMI, the '

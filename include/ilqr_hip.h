@@ -72,8 +72,8 @@ typedef struct ilqr_desc {
                                      iteration i + 1 (which walks the horizon from its end) run overlapped on two HIP
                                      streams, in chunks.  0 auto (on when the horizon gives at least 4 chunks of 4 segments of
                                      64 steps), 1 off, 2 on from two segments up.  Results do not depend on it.  Set 1
-                                     when other PROCESSES use the same GPU: the cross-stream waits were seen to stall then
-                                     (DESIGN.md section 5); one process per GPU, the intended layout, is not affected. */
+                                     when other PROCESSES use the same GPU: two solves stalled in such rehearsals, none with
+                                     this set to 1; one process per GPU is the supported layout. */
     double search_floor;          /* 0.05  the LITERAL in `while learning_rate > 0.05 and armijo_flag == 0` (ilqr.py:185):
                                      trials alpha_j = learning_speed^j run while alpha_j > search_floor.  The reference keeps
                                      it apart from low_learning_rate (:167, used at :204 only); so does this library: a trial
