@@ -354,7 +354,8 @@ def _proportional_divisors(em):
     return out
 
 
-def generate(name):
+def render(name):
+    """(text of the header, lambdify sources) of one system"""
     model = models.BUILDERS[name]()
     n, m, npar = model.n, model.m, model.n_params
     up = name.upper()
@@ -386,7 +387,11 @@ def generate(name):
         parts.append(code)
         srcs[what] = src
     parts.append('#endif')
-    text = '\n\n'.join(parts) + '\n'
+    return '\n\n'.join(parts) + '\n', srcs
+
+
+def generate(name):
+    text, srcs = render(name)
     path = os.path.join(OUT_DIR, name + '.h')
     with open(path, 'w') as fh:
         fh.write(text)

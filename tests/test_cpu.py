@@ -378,3 +378,24 @@ def test_two_rank_shard_and_gather_gloo(tmp_path, oracle):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert 'rank %d ok' % r in o
+
+
+# ------------------------------------------------------------------------------------------ generated dynamics
+def test_committed_dynamics_headers_are_what_the_generator_emits():
+    """ilqr_amd/csrc/dynamics/*.h are generated (codegen/gen_dynamics.py from codegen/models.py): the committed files must be the
+    generator's output, byte for byte, so that a change to either cannot leave the library on stale dynamics.  (codegen/ stays in
+    the build container -- it is not shipped to the GPU box, where this CPU test is not run either.)"""
+    cg = os.path.join(ROOT, 'codegen')
+    if not os.path.isdir(cg):
+        pytest.skip('codegen/ is not present here')
+    pytest.importorskip('sympy')
+    sys.path.insert(0, cg)
+    try:
+        import gen_dynamics
+        import models
+        for name in models.BUILDERS:
+            text, _ = gen_dynamics.render(name)
+            with open(os.path.join(ROOT, 'ilqr_amd', 'csrc', 'dynamics', name + '.h')) as fh:
+                assert fh.read() == text, name
+    finally:
+        sys.path.remove(cg)
