@@ -330,6 +330,113 @@ __device__ __forceinline__ double bcast_row(const double src)
     asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(L));
     return r;
 }
+// Groups of up to four such instructions behind ONE s_nop (accumulators are early-clobber operands: no input of the group may
+// share a register with one of them).  The wait states are needed once per group (the group is one asm
+// statement: no register copy can come between its instructions), and an s_nop is an issue slot like any other -- with
+// one per DPP instruction a third of the group kernel's instruction stream was s_nop.
+//   fmac_row_acc<L>: K accumulators, acc_k += (lane L of src_k) * own
+//   fmac_row_dot<L>: one accumulator, acc += (lane L of src_k) * own_k for k = 0, 1, ... in this order
+#define ILQR_DPP_FMAC(acc, src, own, lane) "v_fmac_f64_dpp " acc ", " src ", " own " row_newbcast:" lane " row_mask:0xf bank_mask:0xf"
+template <int L>
+__device__ __forceinline__ void fmac_row_acc(double& a0, double& a1, const double s0, const double s1, const double o)
+{
+    asm("s_nop 1\n\t" ILQR_DPP_FMAC("%0", "%2", "%4", "%5") "\n\t" ILQR_DPP_FMAC("%1", "%3", "%4", "%5")
+        : "+&v"(a0), "+&v"(a1) : "v"(s0), "v"(s1), "v"(o), "n"(L));
+}
+template <int L>
+__device__ __forceinline__ void fmac_row_acc(double& a0, double& a1, double& a2, const double s0, const double s1, const double s2,
+                                             const double o)
+{
+    asm("s_nop 1\n\t" ILQR_DPP_FMAC("%0", "%3", "%6", "%7") "\n\t" ILQR_DPP_FMAC("%1", "%4", "%6", "%7") "\n\t"
+        ILQR_DPP_FMAC("%2", "%5", "%6", "%7")
+        : "+&v"(a0), "+&v"(a1), "+&v"(a2) : "v"(s0), "v"(s1), "v"(s2), "v"(o), "n"(L));
+}
+template <int L>
+__device__ __forceinline__ void fmac_row_acc(double& a0, double& a1, double& a2, double& a3, const double s0, const double s1,
+                                             const double s2, const double s3, const double o)
+{
+    asm("s_nop 1\n\t" ILQR_DPP_FMAC("%0", "%4", "%8", "%9") "\n\t" ILQR_DPP_FMAC("%1", "%5", "%8", "%9") "\n\t"
+        ILQR_DPP_FMAC("%2", "%6", "%8", "%9") "\n\t" ILQR_DPP_FMAC("%3", "%7", "%8", "%9")
+        : "+&v"(a0), "+&v"(a1), "+&v"(a2), "+&v"(a3) : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(o), "n"(L));
+}
+template <int L>
+__device__ __forceinline__ void fmac_row_dot(double& acc, const double s0, const double s1, const double o0, const double o1)
+{
+    asm("s_nop 1\n\t" ILQR_DPP_FMAC("%0", "%1", "%3", "%5") "\n\t" ILQR_DPP_FMAC("%0", "%2", "%4", "%5")
+        : "+&v"(acc) : "v"(s0), "v"(s1), "v"(o0), "v"(o1), "n"(L));
+}
+template <int L>
+__device__ __forceinline__ void fmac_row_dot(double& acc, const double s0, const double s1, const double s2, const double o0,
+                                             const double o1, const double o2)
+{
+    asm("s_nop 1\n\t" ILQR_DPP_FMAC("%0", "%1", "%4", "%7") "\n\t" ILQR_DPP_FMAC("%0", "%2", "%5", "%7") "\n\t"
+        ILQR_DPP_FMAC("%0", "%3", "%6", "%7")
+        : "+&v"(acc) : "v"(s0), "v"(s1), "v"(s2), "v"(o0), "v"(o1), "v"(o2), "n"(L));
+}
+template <int L>
+__device__ __forceinline__ void fmac_row_dot(double& acc, const double s0, const double s1, const double s2, const double s3,
+                                             const double o0, const double o1, const double o2, const double o3)
+{
+    asm("s_nop 1\n\t" ILQR_DPP_FMAC("%0", "%1", "%5", "%9") "\n\t" ILQR_DPP_FMAC("%0", "%2", "%6", "%9") "\n\t"
+        ILQR_DPP_FMAC("%0", "%3", "%7", "%9") "\n\t" ILQR_DPP_FMAC("%0", "%4", "%8", "%9")
+        : "+&v"(acc) : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "n"(L));
+}
+// acc[OFF + k * STRIDE] += (lane L of src[k]) * own for k < M, in groups of up to four
+template <int L, int M, int STRIDE = 1, int OFF = 0, int K0 = 0, int NA, int NS>
+__device__ __forceinline__ void fmac_row_vec(double (&acc)[NA], const double (&src)[NS], const double own)
+{
+    constexpr int K = M - K0 < 4 ? M - K0 : 4;
+    constexpr int e0 = OFF + K0 * STRIDE, e1 = e0 + STRIDE, e2 = e1 + STRIDE, e3 = e2 + STRIDE;
+    if constexpr (K == 1) fmac_row<L>(acc[e0], src[K0], own);
+    else if constexpr (K == 2) fmac_row_acc<L>(acc[e0], acc[e1], src[K0], src[K0 + 1], own);
+    else if constexpr (K == 3) fmac_row_acc<L>(acc[e0], acc[e1], acc[e2], src[K0], src[K0 + 1], src[K0 + 2], own);
+    else if constexpr (K == 4) fmac_row_acc<L>(acc[e0], acc[e1], acc[e2], acc[e3], src[K0], src[K0 + 1], src[K0 + 2], src[K0 + 3], own);
+    if constexpr (K0 + K < M) fmac_row_vec<L, M, STRIDE, OFF, K0 + K>(acc, src, own);
+}
+// acc += (lane L of src[k]) * own[k] for k = 0 .. M-1, in this order, in groups of up to four
+template <int L, int M, int K0 = 0>
+__device__ __forceinline__ void fmac_row_sum(double& acc, const double (&src)[M], const double (&own)[M])
+{
+    constexpr int K = M - K0 < 4 ? M - K0 : 4;
+    if constexpr (K == 1) fmac_row<L>(acc, src[K0], own[K0]);
+    else if constexpr (K == 2) fmac_row_dot<L>(acc, src[K0], src[K0 + 1], own[K0], own[K0 + 1]);
+    else if constexpr (K == 3) fmac_row_dot<L>(acc, src[K0], src[K0 + 1], src[K0 + 2], own[K0], own[K0 + 1], own[K0 + 2]);
+    else if constexpr (K == 4) fmac_row_dot<L>(acc, src[K0], src[K0 + 1], src[K0 + 2], src[K0 + 3], own[K0], own[K0 + 1], own[K0 + 2], own[K0 + 3]);
+    if constexpr (K0 + K < M) fmac_row_sum<L, M, K0 + K>(acc, src, own);
+}
+// position of the k-th general ('x') entry in row r of A (IS_B: of B) -- the column phase groups a row's entries
+template <class S, bool IS_B>
+constexpr int row_x_count(const int r)
+{
+    int c = 0;
+    for (int i = 0; i < (IS_B ? S::m : S::n); ++i) c += (IS_B ? S::B_pat[r * S::m + i] : S::A_pat[r * S::n + i]) == 'x' ? 1 : 0;
+    return c;
+}
+template <class S, bool IS_B>
+constexpr int row_x_index(const int r, const int k)
+{
+    int c = 0;
+    for (int i = 0; i < (IS_B ? S::m : S::n); ++i)
+        if ((IS_B ? S::B_pat[r * S::m + i] : S::A_pat[r * S::n + i]) == 'x') { if (c == k) return i; ++c; }
+    return 0;
+}
+// acc[i_k] += (lane r of src[i_k]) * own over the general entries i_k of row r, in groups of up to four
+template <class S, bool IS_B, int r, int K0 = 0, int NA>
+__device__ __forceinline__ void fmac_row_pattern(double (&acc)[NA], const double (&src)[NA], const double own)
+{
+    constexpr int M = row_x_count<S, IS_B>(r);
+    if constexpr (K0 < M) {
+        constexpr int K = M - K0 < 4 ? M - K0 : 4;
+        constexpr int i0 = row_x_index<S, IS_B>(r, K0), i1 = row_x_index<S, IS_B>(r, K0 + 1), i2 = row_x_index<S, IS_B>(r, K0 + 2),
+                      i3 = row_x_index<S, IS_B>(r, K0 + 3);
+        if constexpr (K == 1) fmac_row<r>(acc[i0], src[i0], own);
+        else if constexpr (K == 2) fmac_row_acc<r>(acc[i0], acc[i1], src[i0], src[i1], own);
+        else if constexpr (K == 3) fmac_row_acc<r>(acc[i0], acc[i1], acc[i2], src[i0], src[i1], src[i2], own);
+        else fmac_row_acc<r>(acc[i0], acc[i1], acc[i2], acc[i3], src[i0], src[i1], src[i2], src[i3], own);
+        fmac_row_pattern<S, IS_B, r, K0 + K>(acc, src, own);
+    }
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f)
 {
@@ -740,17 +847,15 @@ __global__ void __launch_bounds__(64, Grp<S>::BIGM ? 1 : RICCATI_GRP_WAVES) k_ri
         for (int l = 0; l < m; ++l) BtV[l] = 0.0;
         static_for<0, n>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
+            fmac_row_pattern<S, false, r>(AtV, Ar, Vc[r]);                             // general entries: A[r][i] * V[r][j]
             static_for<0, n>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                constexpr char kd = S::A_pat[r * n + i];
-                if constexpr (kd == 'x') fmac_row<r>(AtV[i], Ar[i], Vc[r]);            // A[r][i] * V[r][j]
-                else if constexpr (kd == '1') AtV[i] = AtV[i] + Vc[r];
+                if constexpr (S::A_pat[r * n + i] == '1') AtV[i] = AtV[i] + Vc[r];
             });
+            fmac_row_pattern<S, true, r>(BtV, Br, Vc[r]);                              // B[r][l] * V[r][j]
             static_for<0, m>([&](auto lc) {
                 constexpr int l = decltype(lc)::value;
-                constexpr char kd = S::B_pat[r * m + l];
-                if constexpr (kd == 'x') fmac_row<r>(BtV[l], Br[l], Vc[r]);            // B[r][l] * V[r][j]
-                else if constexpr (kd == '1') BtV[l] = BtV[l] + Vc[r];
+                if constexpr (S::B_pat[r * m + l] == '1') BtV[l] = BtV[l] + Vc[r];
             });
         });
         if (row) {
@@ -788,10 +893,8 @@ __global__ void __launch_bounds__(64, Grp<S>::BIGM ? 1 : RICCATI_GRP_WAVES) k_ri
             for (int l = 0; l < m; ++l) { Qux[l] = 0.0; qc[l] = 0.0; }
             static_for<0, n>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-#pragma unroll
-                for (int l = 0; l < m; ++l) fmac_row<r>(Qux[l], BtV[l], Acol[r]);       // :101 (B^T V_xx)[l][r] * A[r][i]
-#pragma unroll
-                for (int l = 0; l < m; ++l) fmac_row<r>(qc[l], BtV[l], Bcol[r]);        // :102 (B^T V_xx)[l][r] * B[r][c]
+                fmac_row_vec<r, m>(Qux, BtV, Acol[r]);                                 // :101 (B^T V_xx)[l][r] * A[r][i]
+                fmac_row_vec<r, m>(qc, BtV, Bcol[r]);                                  // :102 (B^T V_xx)[l][r] * B[r][c]
                 fmac_row<r>(Qx, vx, Acol[r]);                                          // :99
                 fmac_row<r>(quc, vx, Bcol[r]);                                         // :100 B[r][c] * V_x[r]
             });
@@ -878,8 +981,7 @@ __global__ void __launch_bounds__(64, Grp<S>::BIGM ? 1 : RICCATI_GRP_WAVES) k_ri
             for (int l = 0; l < m; ++l) KtQuu[l] = 0.0;
             static_for<0, m>([&](auto lc) {                                            // (K' Q_uu)[i][l] = sum_l2 K[l2][i] Q_uu[l2][l]
                 constexpr int l = decltype(lc)::value;
-#pragma unroll
-                for (int l2 = 0; l2 < m; ++l2) fmac_row<l>(KtQuu[l], qo[l2], Kc[l2]);
+                fmac_row_sum<l, m>(KtQuu[l], qo, Kc);
             });
             double v1 = 0.0, v2 = 0.0, v3 = 0.0;                                       // :124
 #pragma unroll
@@ -906,8 +1008,7 @@ __global__ void __launch_bounds__(64, Grp<S>::BIGM ? 1 : RICCATI_GRP_WAVES) k_ri
                     constexpr char kd = S::B_pat[r * m + l2];
                     if constexpr (kd == 'x') {
                         const double Brl = bcast_row<r>(Br[l2]);                       // B[r][l2], the same in every lane
-#pragma unroll
-                        for (int l = 0; l < m; ++l) fmac_row<r>(Quu[l * m + l2], BtV[l], Brl);       // :102
+                        fmac_row_vec<r, m, m, l2>(Quu, BtV, Brl);                      // :102  Quu[l][l2] += (B^T V_xx)[l][r] * B[r][l2]
                         fmac_row<r>(Qu[l2], vx, Brl);                                  // :100 B[r][l2] * V_x[r]
                     } else if constexpr (kd == '1') {
 #pragma unroll
@@ -915,8 +1016,7 @@ __global__ void __launch_bounds__(64, Grp<S>::BIGM ? 1 : RICCATI_GRP_WAVES) k_ri
                         Qu[l2] = Qu[l2] + bcast_row<r>(vx);
                     }
                 });
-#pragma unroll
-                for (int l = 0; l < m; ++l) fmac_row<r>(Qux[l], BtV[l], Acol[r]);       // :101 (B^T V_xx)[l][r] * A[r][i]
+                fmac_row_vec<r, m>(Qux, BtV, Acol[r]);                                 // :101 (B^T V_xx)[l][r] * A[r][i]
                 fmac_row<r>(Qx, vx, Acol[r]);                                          // :99  A[r][i] * V_x[r]
             });
 #pragma unroll
@@ -1025,19 +1125,15 @@ __global__ void __launch_bounds__(64, Grp<S>::BIGM ? 1 : RICCATI_GRP_WAVES) k_ri
             const double Qxx = sQk[cc * n + j] + acc;
             if constexpr (LTV) {                                                       // ltvlqr.py:27
                 double corr = 0.0;
-#pragma unroll
-                for (int l = 0; l < m; ++l) fmac_row<j>(corr, Qux[l], wl[l]);           // w[i][l] * (B'PA)[l][j]
+                fmac_row_sum<j, m>(corr, Qux, wl);                                     // w[i][l] * (B'PA)[l][j]
                 const double Pij = Qxx - corr;
                 if (row) s[G::oT + c * LD + j] = Pij;
                 return;
             }
             double t1 = 0.0, t2 = 0.0, t3 = 0.0;
-#pragma unroll
-            for (int l = 0; l < m; ++l) fmac_row<j>(t1, Kc[l], Qux[l]);                // Q_ux[l][i] * K[l][j]
-#pragma unroll
-            for (int l = 0; l < m; ++l) fmac_row<j>(t2, Qux[l], Kc[l]);                // K[l][i] * Q_ux[l][j]
-#pragma unroll
-            for (int l = 0; l < m; ++l) fmac_row<j>(t3, Kc[l], KtQuu[l]);              // (K^T Q_uu)[i][l] * K[l][j]
+            fmac_row_sum<j, m>(t1, Kc, Qux);                                           // Q_ux[l][i] * K[l][j]
+            fmac_row_sum<j, m>(t2, Qux, Kc);                                           // K[l][i] * Q_ux[l][j]
+            fmac_row_sum<j, m>(t3, Kc, KtQuu);                                         // (K^T Q_uu)[i][l] * K[l][j]
             const double Vij = ((Qxx + t1) + t2) + t3;
             if (row) s[G::oT + c * LD + j] = Vij;                                      // rows -> columns, part 1
         });
