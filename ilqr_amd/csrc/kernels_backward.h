@@ -437,6 +437,60 @@ __device__ __forceinline__ void fmac_row_pattern(double (&acc)[NA], const double
     }
 }
 
+// one accumulator, one source register, lanes L0, L1, ...: acc += (lane L_k of src) * own_k, in this order
+template <int L0, int L1>
+__device__ __forceinline__ void fmac_lanes(double& acc, const double src, const double o0, const double o1)
+{
+    asm("s_nop 1\n\t" ILQR_DPP_FMAC("%0", "%1", "%2", "%4") "\n\t" ILQR_DPP_FMAC("%0", "%1", "%3", "%5")
+        : "+&v"(acc) : "v"(src), "v"(o0), "v"(o1), "n"(L0), "n"(L1));
+}
+template <int L0, int L1, int L2>
+__device__ __forceinline__ void fmac_lanes(double& acc, const double src, const double o0, const double o1, const double o2)
+{
+    asm("s_nop 1\n\t" ILQR_DPP_FMAC("%0", "%1", "%2", "%5") "\n\t" ILQR_DPP_FMAC("%0", "%1", "%3", "%6") "\n\t"
+        ILQR_DPP_FMAC("%0", "%1", "%4", "%7")
+        : "+&v"(acc) : "v"(src), "v"(o0), "v"(o1), "v"(o2), "n"(L0), "n"(L1), "n"(L2));
+}
+template <int L0, int L1, int L2, int L3>
+__device__ __forceinline__ void fmac_lanes(double& acc, const double src, const double o0, const double o1, const double o2,
+                                           const double o3)
+{
+    asm("s_nop 1\n\t" ILQR_DPP_FMAC("%0", "%1", "%2", "%6") "\n\t" ILQR_DPP_FMAC("%0", "%1", "%3", "%7") "\n\t"
+        ILQR_DPP_FMAC("%0", "%1", "%4", "%8") "\n\t" ILQR_DPP_FMAC("%0", "%1", "%5", "%9")
+        : "+&v"(acc) : "v"(src), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "n"(L0), "n"(L1), "n"(L2), "n"(L3));
+}
+// column j of A walked over its rows r in order: general entries acc += (lane r of src) * own[r] in runs of up to four that
+// no unit entry interrupts (a unit entry is acc += own[r] and keeps its place in the order of the sum)
+template <class S>
+constexpr int col_next(const int j, int r)            // first row >= r whose entry in column j is not a structural zero
+{
+    while (r < S::n && S::A_pat[r * S::n + j] == '0') ++r;
+    return r;
+}
+template <class S, int j, int r0 = 0>
+__device__ __forceinline__ void fmac_col_pattern(double& acc, const double src, const double (&own)[S::n])
+{
+    constexpr int n = S::n;
+    constexpr int a = col_next<S>(j, r0);
+    if constexpr (a < n) {
+        if constexpr (S::A_pat[a * n + j] == '1') {
+            acc = acc + own[a];
+            fmac_col_pattern<S, j, a + 1>(acc, src, own);
+        } else {
+            constexpr int b = col_next<S>(j, a + 1);
+            constexpr bool xb = b < n && S::A_pat[(b < n ? b : 0) * n + j] == 'x';
+            constexpr int c = xb ? col_next<S>(j, b + 1) : n;
+            constexpr bool xc = xb && c < n && S::A_pat[(c < n ? c : 0) * n + j] == 'x';
+            constexpr int d = xc ? col_next<S>(j, c + 1) : n;
+            constexpr bool xd = xc && d < n && S::A_pat[(d < n ? d : 0) * n + j] == 'x';
+            if constexpr (xd) { fmac_lanes<a, b, c, d>(acc, src, own[a], own[b], own[c], own[d]); fmac_col_pattern<S, j, d + 1>(acc, src, own); }
+            else if constexpr (xc) { fmac_lanes<a, b, c>(acc, src, own[a], own[b], own[c]); fmac_col_pattern<S, j, c + 1>(acc, src, own); }
+            else if constexpr (xb) { fmac_lanes<a, b>(acc, src, own[a], own[b]); fmac_col_pattern<S, j, b + 1>(acc, src, own); }
+            else { fmac_row<a>(acc, src, own[a]); fmac_col_pattern<S, j, a + 1>(acc, src, own); }
+        }
+    }
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f)
 {
@@ -922,11 +976,10 @@ __global__ void __launch_bounds__(64, Grp<S>::BIGM ? 1 : RICCATI_GRP_WAVES) k_ri
                 for (int l = 0; l < m; ++l) b2[l] = 0.0;
                 static_for<0, n>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
+                    fmac_row_pattern<S, true, r>(b2, Br, Ri0[r]);
                     static_for<0, m>([&](auto lc) {
                         constexpr int l = decltype(lc)::value;
-                        constexpr char kd = S::B_pat[r * m + l];
-                        if constexpr (kd == 'x') fmac_row<r>(b2[l], Br[l], Ri0[r]);
-                        else if constexpr (kd == '1') b2[l] = b2[l] + Ri0[r];
+                        if constexpr (S::B_pat[r * m + l] == '1') b2[l] = b2[l] + Ri0[r];
                     });
                 });
             }
@@ -1098,11 +1151,10 @@ __global__ void __launch_bounds__(64, Grp<S>::BIGM ? 1 : RICCATI_GRP_WAVES) k_ri
             for (int l = 0; l < m; ++l) apb[l] = 0.0;
             static_for<0, n>([&](auto rc) {                                            // (A'PB)[i][l] = sum_r (A'P)[i][r] B[r][l]
                 constexpr int r = decltype(rc)::value;
+                fmac_row_pattern<S, true, r>(apb, Br, Ri[r]);
                 static_for<0, m>([&](auto lc) {
                     constexpr int l = decltype(lc)::value;
-                    constexpr char kd = S::B_pat[r * m + l];
-                    if constexpr (kd == 'x') fmac_row<r>(apb[l], Br[l], Ri[r]);
-                    else if constexpr (kd == '1') apb[l] = apb[l] + Ri[r];
+                    if constexpr (S::B_pat[r * m + l] == '1') apb[l] = apb[l] + Ri[r];
                 });
             });
 #pragma unroll
@@ -1116,12 +1168,7 @@ __global__ void __launch_bounds__(64, Grp<S>::BIGM ? 1 : RICCATI_GRP_WAVES) k_ri
         static_for<0, n>([&](auto jc) {                                                // registers ended with the column phase)
             constexpr int j = decltype(jc)::value;
             double acc = 0.0;
-            static_for<0, n>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                constexpr char kd = S::A_pat[r * n + j];
-                if constexpr (kd == 'x') fmac_row<r>(acc, Aw[j], Ri[r]);               // (A^T V_xx)[i][r] * A[r][j]
-                else if constexpr (kd == '1') acc = acc + Ri[r];
-            });
+            fmac_col_pattern<S, j>(acc, Aw[j], Ri);                                    // sum over r of (A^T V_xx)[i][r] * A[r][j]
             const double Qxx = sQk[cc * n + j] + acc;
             if constexpr (LTV) {                                                       // ltvlqr.py:27
                 double corr = 0.0;
