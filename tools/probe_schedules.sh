@@ -1,6 +1,6 @@
-for S in "4,4,8,16" "8,8,16" "1,1,2,4,8,16,32" "2,2,4,8,16,32" "4,4,8,16,32" "8,8,16,32" "4,4,8,8,8,16"; do
-  echo "== $S"
-  ILQR_LS_SCHEDULE=$S timeout -k 10 200 python tools/probe_big.py cartpole 131072 2>&1 | grep -E "solves/s" | tail -1 || exit 1
-  ILQR_LS_SCHEDULE=$S timeout -k 10 200 python tools/probe_big.py pendulum 131072 2>&1 | grep -E "solves/s" | tail -1 || exit 1
-  ILQR_LS_SCHEDULE=$S timeout -k 10 200 python tools/probe_big.py acrobot 65536 2>&1 | grep -E "solves/s" | tail -1 || exit 1
+# Development aid (run on the GPU box): line-search round schedules (ILQR_LS_SCHEDULE) on the large-batch configurations.
+for s in "4,4,8,16,16,16" "8,8,8,8,8,8,8,8" "4,4,8,8,8,8,8,8,8" "8,8,8,8,16,16" "4,4,8,8,8,16,16"; do
+  for c in acrobot_big c4 pendulum; do
+    ILQR_LS_SCHEDULE=$s timeout -k 10 200 python bench.py --no-extra --steps 2 --warmup 1 --config $c 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], sys.argv[2], round(d['value']), d['ms_per_step'], d['kernels']['linesearch']['ms_per_pass'])" "$s" $c || exit 1
+  done
 done
