@@ -399,3 +399,28 @@ def test_committed_dynamics_headers_are_what_the_generator_emits():
                 assert fh.read() == text, name
     finally:
         sys.path.remove(cg)
+
+
+# ------------------------------------------------------------------------------------------ emitted code
+def test_no_dpp_read_after_valu_write_hazard_in_the_built_library():
+    """The group recursion's row broadcasts are inline asm (v_fmac_f64_dpp / v_mov_b64_dpp row_newbcast): the compiler does not
+    insert the two wait states a DPP read of a freshly written VGPR needs, the kernels do (one s_nop per instruction or group).
+    tools/check_dpp_hazards.py proves it on the instructions actually emitted -- here first on two hand-made listings (the
+    checker must see a hazard where there is one), then on the library itself."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        import check_dpp_hazards as chk
+    finally:
+        sys.path.pop(0)
+    dpp = 'v_fmac_f64_dpp v[0:1], v[4:5], v[6:7] row_newbcast:3 row_mask:0xf bank_mask:0xf'
+    hazard = '0000 <k>:\n\tv_mul_f64 v[4:5], v[8:9], v[10:11]\n\tv_add_f64 v[20:21], v[8:9], v[10:11]\n\t' + dpp + '\n'
+    assert chk.check(hazard) == (1, [('k', dpp)])                                   # one instruction in between: one wait state
+    for fix in ('\ts_nop 1\n', '\tv_add_f64 v[22:23], v[8:9], v[10:11]\n\tv_add_f64 v[24:25], v[8:9], v[10:11]\n'):
+        ok = '0000 <k>:\n\tv_mul_f64 v[4:5], v[8:9], v[10:11]\n' + fix + '\t' + dpp + '\n'
+        assert chk.check(ok) == (1, [])
+    assert chk.check('0000 <k>:\n\tv_mul_f64 v[6:7], v[8:9], v[10:11]\n\t' + dpp + '\n') == (1, [])   # own operand: no DPP read
+    lib = os.path.join(ROOT, 'ilqr_amd', 'libilqr_hip.so')
+    if not (os.path.exists(chk.OBJDUMP) and os.path.exists(lib)):
+        pytest.skip('llvm-objdump or the built library is not available here')
+    checked, bad = chk.check(chk.disassemble(lib))
+    assert checked > 1000 and bad == [], bad[:5]
