@@ -231,7 +231,54 @@ def _function(model, what, mat):
     lines.append('}')
     if what == 'f':
         lines += _function_f_sc(model, em, els, sums)
+    else:
+        lines += _function_jac_sc(model, what, em, els)
     return '\n'.join(lines), src
+
+
+def _function_jac_sc(model, what, em, els):
+    """A or B once more for callers that carry the sin/cos pairs of the f_ang state components along a trajectory (the ltvlqr
+    recursion walking a given trajectory backwards): those pairs come in through `sc` as in f_sc, the pair of a sum of two
+    of them is plain angle addition, everything else -- other arguments, tan, every divisor -- is as in the plain function.
+    The Jacobians' entries are dt * expression (plus a structural one): a trig value's last bits reach them scaled by dt."""
+    f_ang = model._f_ang
+    slot, sums, direct = {}, {}, []
+    for arg, i in em.trig_args:
+        m = re.fullmatch(r'x\[(\d+)\]', arg)
+        if m and int(m.group(1)) in f_ang:
+            slot[i] = f_ang.index(int(m.group(1)))
+    for arg, i in em.trig_args:
+        for a, ia in em.trig_args:
+            for b, ib in em.trig_args:
+                if arg == '(%s + %s)' % (a, b) and ia in slot and ib in slot and i not in slot:
+                    sums[i] = (a, ia, b, ib)
+    lines = ['', 'ILQR_DYN_FN void ilqr_dyn_%s_%s_sc(const double* x, const double* u, const double dt, const double* p, '
+             'const double* sc, double* out)' % (model.name, what), '{', '    (void)x; (void)u; (void)dt; (void)p; (void)sc;']
+    for arg, i in em.trig_args:
+        if i in slot:
+            lines.append('    const double sn%d = sc[%d], cs%d = sc[%d]; (void)sn%d; (void)cs%d;' % (i, 2 * slot[i], i, 2 * slot[i] + 1, i, i))
+        elif i not in sums:
+            lines.append('    double sn%d, cs%d; ILQR_DYN_SINCOS(%s, sn%d, cs%d); (void)sn%d; (void)cs%d;' % (i, i, arg, i, i, i, i))
+            direct.append((arg, i))
+    for i, (a, ia, b, ib) in sorted(sums.items()):
+        lines.append('    double sn%d, cs%d; ILQR_DYN_SINCOS_SUM_SC(%s, %s, sn%d, cs%d, sn%d, cs%d, sn%d, cs%d); (void)sn%d; (void)cs%d;'
+                     % (i, i, a, b, ia, ia, ib, ib, i, i, i, i))
+    if direct:
+        lines.append('    if (%s) {' % ' || '.join('ILQR_DYN_TRIG_BIG(%s)' % a for a, i in direct))
+        for a, i in direct:
+            lines.append('        ILQR_DYN_SINCOS_SLOW(%s, sn%d, cs%d);' % (a, i, i))
+        lines.append('    }')
+    for i, arg in em.tan_defs:
+        lines.append('    const double tn%d = ILQR_DYN_TAN(%s);' % (i, arg))
+    for d in em.rcp_defs:
+        lines.append('    ' + d)
+    k = 0
+    for row in els:
+        for e in row:
+            lines.append('    out[%d] = %s;' % (k, e))
+            k += 1
+    lines.append('}')
+    return lines
 
 
 def _function_f_sc(model, em, els, sums):
@@ -247,6 +294,7 @@ def _function_f_sc(model, em, els, sums):
         if m and i not in sums:
             carried.append((int(m.group(1)), i))
     slot = {i: k for k, (_, i) in enumerate(carried)}
+    model._f_ang = [a for a, _ in carried]     # (the Jacobians' _sc variants, generated after f, take the same pairs)
     lines = ['', '#define ILQR_DYN_%s_F_NANG %d' % (up, len(carried)),
              '/* state components whose sin/cos pair the caller of f_sc carries */',
              'ILQR_DYN_CONST int ilqr_dyn_%s_f_ang[%d] = {%s};' % (model.name, max(len(carried), 1),

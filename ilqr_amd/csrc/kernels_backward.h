@@ -1231,6 +1231,14 @@ __global__ void __launch_bounds__(64) k_ltvlqr(const KArgs a)
         load_col<n>(Xp + (size_t)tl * n * TILE, xr[d]);
         load_col<m>(Up + (size_t)tl * m * TILE, ur[d]);
     }
+    // The trajectory is walked row by row: the sin/cos pairs of its angle states are carried from row t + 1 to row t by
+    // angle addition on the difference of the two rows (TrigCarry: evaluated afresh at the last row, at every multiple of
+    // the checkpoint interval and whenever two rows are further apart than 2^-4 rad), instead of two range reductions and
+    // polynomial pairs per row.  A_t and B_t are I + dt * (...): a trig value's last bits reach them scaled by dt.
+    TrigCarry<S> trig;
+    double xnext[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) xnext[i] = 0.0;
     for (int t0 = a.N - 1; t0 >= 0; t0 -= D) {                                         // :15
 #pragma unroll
       for (int d = 0; d < D; ++d) {
@@ -1242,8 +1250,16 @@ __global__ void __launch_bounds__(64) k_ltvlqr(const KArgs a)
 #pragma unroll
         for (int j = 0; j < m; ++j) u[j] = ur[d][j];
         double A[n * n], Bm[n * m];
-        S::A(x, u, a.dt, p, A);                                                        // :21
-        S::B(x, u, a.dt, p, Bm);                                                       // :22
+        if constexpr (S::n_ang > 0) {
+            trig.advance(xnext, x, t == a.N - 1 || (t + 1) % a.ck == 0);
+#pragma unroll
+            for (int i = 0; i < n; ++i) xnext[i] = x[i];
+            S::A_sc(x, u, a.dt, p, trig.sc, A);                                        // :21
+            S::B_sc(x, u, a.dt, p, trig.sc, Bm);                                       // :22
+        } else {
+            S::A(x, u, a.dt, p, A);                                                    // :21
+            S::B(x, u, a.dt, p, Bm);                                                   // :22
+        }
         {
             const int tl = t - D > 0 ? t - D : 0;                                      // slot d next holds step t - D
             load_col<n>(Xp + (size_t)tl * n * TILE, xr[d]);

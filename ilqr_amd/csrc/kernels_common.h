@@ -44,6 +44,13 @@ constexpr int N_KERNEL_IDS = 8;
                                                  double* o) { ilqr_dyn_##NAME##_A(x, u, dt, p, o); }              \
         static __device__ __forceinline__ void B(const double* x, const double* u, double dt, const double* p,   \
                                                  double* o) { ilqr_dyn_##NAME##_B(x, u, dt, p, o); }              \
+        /* the Jacobians with the carried pairs handed in (a trajectory walked step by step: k_ltvlqr) */         \
+        static __device__ __forceinline__ void A_sc(const double* x, const double* u, double dt, const double* p, \
+                                                    const double* sc, double* o)                                  \
+        { ilqr_dyn_##NAME##_A_sc(x, u, dt, p, sc, o); }                                                           \
+        static __device__ __forceinline__ void B_sc(const double* x, const double* u, double dt, const double* p, \
+                                                    const double* sc, double* o)                                  \
+        { ilqr_dyn_##NAME##_B_sc(x, u, dt, p, sc, o); }                                                           \
     };
 ILQR_DEFINE_SYSTEM(pendulum, PENDULUM, 1, false)
 ILQR_DEFINE_SYSTEM(acrobot, ACROBOT, 1, false)
