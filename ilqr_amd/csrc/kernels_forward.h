@@ -399,11 +399,14 @@ __device__ __forceinline__ double closed_loop_staged(const KArgs& a, double* sw,
 #ifndef LS_WAVES_SMALL
 #define LS_WAVES_SMALL 2
 #endif
+#ifndef LS_WAVES_ACROBOT
+#define LS_WAVES_ACROBOT 2
+#endif
 constexpr int LS_STILL_SEARCHING = -2;   // acc_j between rounds: no trial accepted yet, more rounds to come
 template <class S>
 constexpr int ls_waves_per_simd()
 {
-    return S::n > 4 ? 1 : (S::id == ILQR_DYN_ACROBOT_ID ? 2 : LS_WAVES_SMALL);   // (4 for cartpole spills 14 VGPRs and gains nothing)
+    return S::n > 4 ? 1 : (S::id == ILQR_DYN_ACROBOT_ID ? LS_WAVES_ACROBOT : LS_WAVES_SMALL);   // (4 for cartpole spills 14 VGPRs and gains nothing)
 }
 template <class S, int W, bool CKPT, bool TRACK = false>
 __global__ void __launch_bounds__(W == 64 ? 512 : 256, ls_waves_per_simd<S>()) k_linesearch(const KArgs a)

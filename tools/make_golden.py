@@ -22,6 +22,9 @@ Fixtures (all float64, reference numpy layout):
   <sys>_batch.npz          8 seeded problems, short horizon, n_iterations=3, solved one by one
   acrobot_solve10.npz      the acrobot example stopped after 10 iterations (the bench's fixed iteration count; problem 0 of
                            the headline batch): `python tools/make_golden.py solve10`
+  {c2,c4,c5}_sample.npz    the first 32 / 16 / 8 problems of bench.py's random C2 / C4 / C5 batches (bench.workload, seed 0) solved
+                           by the reference class at the bench's 10 iterations, in parallel worker processes; trace, cost, exit
+                           status in full, states / inputs / gains subsampled in time: `python tools/make_golden.py samples`
 """
 import contextlib
 import io
@@ -365,8 +368,66 @@ def gen_ltvlqr(fabs, pend_solve):
                  np.array([-np.pi / 4, 0]), 0.005, p)
 
 
+SAMPLES = {'c2': ('acrobot', 32, 32), 'c4': ('cartpole', 16, 16), 'c5': ('quadcopter', 8, 8)}   # system, problems, time stride
+_SAMPLE_FAB = {}
+
+
+def _sample_worker(job):
+    """one problem of a bench batch through the reference class (a worker process; the lambdified model is built once)"""
+    system, idx, c = job
+    if system not in _SAMPLE_FAB:
+        _SAMPLE_FAB[system] = lambdified(system)
+    t = time.time()
+    r = run_solve(make(c, _SAMPLE_FAB[system]))
+    return idx, r, time.time() - t
+
+
+def gen_samples(which):
+    """The random bench batches pinned to the reference itself (bench.workload(name, B, 0): problems 0 .. count-1)."""
+    import multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    import bench
+    jobs, meta = [], {}
+    for name in which:
+        system, count, stride = SAMPLES[name]
+        w = bench.workload(name, bench.DEFAULT_BATCH[name], 0)
+        N = w['N']
+        meta[name] = (w, count, stride)
+        for b in range(count):
+            target = w['target'][b] if np.ndim(w['target']) == 2 else w['target']
+            c = dict(dt=w['dt'], start=0, end=N * w['dt'] - w['dt'] / 2, init=w['init'][b].copy(), target=np.array(target, float),
+                     guess=w['guess'][b].copy(), Qk=w['Qk'], Rk=w['Rk'], QT=w['QT'], params=w['params'], n_iterations=w['n_iterations'])
+            assert np.arange(c['start'], c['end'], c['dt']).shape[0] == N
+            jobs.append((system, (name, b), c))
+    res = {}
+    with mp.Pool(min(7, len(jobs))) as pool:
+        for (name, b), r, secs in pool.imap_unordered(_sample_worker, jobs):
+            res[(name, b)] = r
+            print('  %s problem %2d: %d iterations, status %d, cost %.16g (%.1f s)' % (name, b, r['iters'], r['status'], r['cost'], secs),
+                  flush=True)
+    for name in which:
+        w, count, stride = meta[name]
+        rs = [res[(name, b)] for b in range(count)]
+        n_it = w['n_iterations']
+        trace = np.full((count, n_it, 6), np.nan)
+        for b, r in enumerate(rs):
+            trace[b, :r['trace'].shape[0]] = r['trace']
+        N = w['N']
+        ts = np.unique(np.concatenate([np.arange(0, N, stride), [N - 1]]))        # rows of inputs / gains kept
+        tx = np.unique(np.concatenate([np.arange(0, N + 1, stride), [N]]))        # rows of states kept
+        save(name + '_sample', config=np.array(list(name.encode()), np.uint8), count=np.int32(count), n_iterations=np.int32(n_it),
+             init=w['init'][:count], guess_checksum=np.array([float(np.sum(w['guess'][b] * np.arange(1, N + 1)[:, None])) for b in range(count)]),
+             rows_inputs=ts, rows_states=tx, cost=np.array([r['cost'] for r in rs]), status=np.array([r['status'] for r in rs], np.int32),
+             iters=np.array([r['iters'] for r in rs], np.int32), trace=trace,
+             states=np.stack([r['states'][tx] for r in rs]), inputs=np.stack([r['inputs'][ts] for r in rs]),
+             k=np.stack([r['k'][ts] for r in rs]), K=np.stack([r['K'][ts] for r in rs]))
+
+
 def main():
     only = set(sys.argv[1:])
+    if only and only <= {'samples', 'c2sample', 'c4sample', 'c5sample'}:
+        gen_samples(['c2', 'c4', 'c5'] if 'samples' in only else sorted(o[:2] for o in only))
+        return
     if only == {'solve10'}:           # the acrobot example with n_iterations = 10 (BASELINE configs[1] runs 10 iterations)
         c = dict(CONFIG['acrobot'](), n_iterations=10)
         r = run_solve(make(c, lambdified('acrobot')))

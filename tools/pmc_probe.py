@@ -1,21 +1,35 @@
 #!/usr/bin/env python3
-"""Workload for rocprofv3 --pmc passes: one C2 solve (bench workload) + calibration kernels with known byte counts.
-k_cost reads U (B*N*m*8 bytes) and one row of X; k_rollout reads G and writes X and U."""
-import os, sys
-import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench, ilqr_amd
-from ilqr_amd import _lib
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-cfg = bench.acrobot_c2(B, 0)
-ws = ilqr_amd.Workspace('acrobot', cfg['N'], B, cfg['dt'], want_trace=True, n_iterations=10)
-ws.set_weights(cfg['Qk'], cfg['Rk'], cfg['QT'])
-for f, a in ((_lib.F_INIT, cfg['init']), (_lib.F_TARGET, cfg['target']), (_lib.F_PARAMS, cfg['params']), (_lib.F_GUESS, cfg['guess'])):
-    ws.upload(f, a)
-ws.solve(); ws.sync()
+"""Workload for rocprofv3 --pmc passes: ONE step of a bench configuration (bench.workload / bench.make_workspace, the very
+objects bench.py times) + for c2 a k_cost launch as a calibration kernel with a known byte count (it reads U: B*N*m*8 bytes).
+usage: python tools/pmc_probe.py [config [B]]      config = c2 (default) | c3 | c4 | c4_w8 | c5 | pendulum | acrobot_big | ...
+Prints a CONFIG line (what tools/summarize_pmc.py writes into the traffic file bench.py matches against) and the launch
+order of the line-search rounds (widths), so the summariser can tell the rounds of one search apart."""
+import argparse
 import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+import ilqr_amd
+from ilqr_amd import _lib
+
+name = sys.argv[1] if len(sys.argv) > 1 else 'c2'
+B = int(sys.argv[2]) if len(sys.argv) > 2 else bench.DEFAULT_BATCH[name]
+args = argparse.Namespace(alphas=0, streams=0, riccati=0, overlap=None, device_wrap=False)
+cfg = bench.workload(name, B, 0)
+ws = bench.make_workspace(cfg, B, 0, args)
+one = {'ltvlqr': ws.ltvlqr, 'mpc': lambda: (ws.mpc_shift(1), ws.mpc_solve(False))}.get(cfg['kind'], ws.solve)
+one()
+ws.sync()
 info = ws.info()
-print('CONFIG ' + json.dumps(dict(system='acrobot', batch=B, n_timesteps=cfg['N'], n_alpha_parallel=info['n_alpha_parallel'], pipeline=info['pipeline'])))
-ws.cost(); ws.sync()
-tr = ws.download(_lib.F_TRACE)
-print('rounds', int(ws.download(_lib.F_LS_ROUNDS).sum()), 'accepts', int(ws.download(_lib.F_ACCEPTS).sum()), 'bwd', int(ws.download(_lib.F_ITERS).sum()))
+print('CONFIG ' + json.dumps(dict(name=name, system=cfg['system'], batch=B, n_timesteps=cfg['N'], n_alpha_parallel=info['n_alpha_parallel'],
+                                  pipeline=info['pipeline'], ls_widths=info['ls_widths'], kind=cfg['kind'])))
+if cfg['kind'] == 'solve':
+    if name == 'c2':
+        ws.cost()
+        ws.sync()
+    print('rounds', int(ws.download(_lib.F_LS_ROUNDS).sum()), 'accepts', int(ws.download(_lib.F_ACCEPTS).sum()), 'bwd',
+          int(ws.download(_lib.F_ITERS).sum()))
