@@ -894,9 +894,12 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
     if (ws->n_chunks < (d->overlap == 2 ? 2 : 4)) ws->overlap = 0;
     ws->n_lin = with_system(d->system_id, [&](auto S) { return Lin<decltype(S)>::n_lin; });
     const size_t Bp = (size_t)ws->Bpad, n = ws->n, m = ws->m, np = ws->np, N = ws->N;
+    const size_t pad = (size_t)LS_GATHER_PAD_STEPS * TILE * 8;          // bytes per component row x padded steps
     struct { void** p; size_t bytes; } allocs[] = {
-        {(void**)&ws->X, Bp * (N + 1) * n * 8}, {(void**)&ws->U, Bp * N * m * 8}, {(void**)&ws->G, Bp * N * m * 8}, {(void**)&ws->KFB, Bp * N * m * n * 8},
-        {(void**)&ws->KFF, Bp * N * m * 8}, {(void**)&ws->INIT, Bp * n * 8}, {(void**)&ws->TARGET, Bp * n * 8},
+        // (+ pad: the line search's cooperative record loads run a few time steps ahead of the step they serve and read, never
+        // use, up to LS_GATHER_PAD_STEPS rows behind the last tile's last step -- kernels_forward.h closed_loop_gather)
+        {(void**)&ws->X, Bp * (N + 1) * n * 8 + pad * n}, {(void**)&ws->U, Bp * N * m * 8 + pad * m}, {(void**)&ws->G, Bp * N * m * 8},
+        {(void**)&ws->KFB, Bp * N * m * n * 8 + pad * m * n}, {(void**)&ws->KFF, Bp * N * m * 8 + pad * m}, {(void**)&ws->INIT, Bp * n * 8}, {(void**)&ws->TARGET, Bp * n * 8},
         {(void**)&ws->PARAMS, Bp * np * 8}, {(void**)&ws->WTS, (2 * n * n + m * m) * 8}, {(void**)&ws->alphas, MAX_TRIALS * 8},
         {(void**)&ws->alpha_pp, Bp * 8}, {(void**)&ws->cost, Bp * 8}, {(void**)&ws->new_cost, Bp * 8}, {(void**)&ws->dJ, 3 * Bp * 8},
         {(void**)&ws->active, Bp * 4}, {(void**)&ws->iters, Bp * 4}, {(void**)&ws->status, Bp * 4}, {(void**)&ws->acc_j, Bp * 4},

@@ -391,6 +391,149 @@ __device__ __forceinline__ double closed_loop_staged(const KArgs& a, double* sw,
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same idea for SMALL records (n <= 4: 6 to 16 doubles) at the narrow widths the large batches start with (W = 4, 8,
+// 16: 16, 8, 4 problems per wave).  There the register path issues one load per component and step whose 64 lanes hold
+// only 64 / W distinct doubles, and rocprofv3 (profiles/r3_*) showed all three large-batch configurations pinned at the same
+// 2.3e10 such instructions per second -- 2.95 TB/s, VALU 35-58 % busy, whatever the prefetch depth or occupancy
+// (tools/probe/ls_load_probe.hip: that pattern caps at 3.1 TB/s, the same lines fetched by fully distinct lanes run at 6.3).
+// Here lane l fetches component l/G (+W, +2W) of problem l%G -- ceil(REC / W) loads per step instead of REC, every lane a
+// different double -- D steps ahead into a small register ring (3 doubles per slot at W = 4 instead of 10), hands the
+// record over through LDS two steps ahead of its use (double buffered) and reads its problem's record back one step ahead.
+// The rows a lane reads beyond step N - 1 exist (LS_GATHER_PAD_STEPS rows of padding behind every trajectory array) and
+// are never consumed.  Same arithmetic in the same order as closed_loop_range: bit-identical trials.
+// ------------------------------------------------------------------------------------------------
+#ifndef LS_GATHER
+#define LS_GATHER 1
+#endif
+#ifndef LS_GATHER_DEPTH
+#define LS_GATHER_DEPTH 4
+#endif
+#ifndef LS_GATHER_MAXW
+#define LS_GATHER_MAXW 64
+#endif
+constexpr int LS_GATHER_PAD_STEPS = 16;      // >= LS_GATHER_DEPTH + 3: rows readable behind the last time step of X, U, KFB, KFF
+template <class S, int W>
+struct Gather {
+    static constexpr int n = S::n, m = S::m, G = TILE / W;
+    static constexpr int REC = n + 2 * m + m * n, RECP = (REC + 1) | 1;  // odd stride >= REC + 1: slot REC takes the idle lanes' stores
+    static constexpr int oX = 0, oU = n, oK = n + m, ok = n + m + m * n;
+    static constexpr int Q = (REC + W - 1) / W;                          // loads per lane and step
+    static constexpr int D = LS_GATHER_DEPTH;                            // steps in flight from HBM
+    static constexpr int BUF = G * RECP, WAVE_DOUBLES = 2 * BUF;
+    static constexpr bool use = LS_GATHER && REC <= 16 && W >= 4 && W <= LS_GATHER_MAXW;
+    static_assert(D % 2 == 0 && D + 3 <= LS_GATHER_PAD_STEPS, "ring depth");
+};
+
+template <class S, int W, bool CKPT>
+__device__ __forceinline__ double closed_loop_gather(const KArgs& a, double* sw, const int lane, const int grp,
+                                                     const long long b_duty, double* ckp, const bool valid,
+                                                     double (&x)[S::n], const double (&p)[S::np],
+                                                     const double (&Rk)[S::m * S::m], const double alpha,
+                                                     const double kill_at)
+{
+    using T = Gather<S, W>;
+    constexpr int n = S::n, m = S::m, G = T::G, RECP = T::RECP, Q = T::Q, D = T::D, REC = T::REC;
+    const int gd = lane % G, cd = lane / G;                                            // load duty: problem gd, components cd + W q
+    const long long tile_d = b_duty >> 6;
+    const int pl_d = (int)(b_duty & 63);
+    // per load q: where this lane's component lives, how far it moves per time step, and its slot in the LDS record
+    const double* src[Q];
+    long long stride[Q];
+    int slot[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int c0 = cd + W * q, c = c0 < REC ? c0 : REC - 1;
+        slot[q] = gd * RECP + (c0 < REC ? c0 : REC);
+        if (c < T::oU) {
+            src[q] = a.X + (size_t)tile_d * a.state_rows * n * TILE + pl_d + (size_t)c * TILE; stride[q] = n * TILE;
+        } else if (c < T::oK) {
+            src[q] = a.U + (size_t)tile_d * a.N * m * TILE + pl_d + (size_t)(c - T::oU) * TILE; stride[q] = m * TILE;
+        } else if (c < T::ok) {
+            src[q] = a.KFB + (size_t)tile_d * a.N * (m * n) * TILE + pl_d + (size_t)(c - T::oK) * TILE; stride[q] = m * n * TILE;
+        } else {
+            src[q] = a.KFF + (size_t)tile_d * a.N * m * TILE + pl_d + (size_t)(c - T::ok) * TILE; stride[q] = m * TILE;
+        }
+    }
+    double ring[D][Q];                                                                 // slot s holds a step congruent to s mod D
+    auto fetch = [&](const int s) __attribute__((always_inline)) {                     // the next step of the stream into slot s
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { ring[s][q] = *src[q]; src[q] += stride[q]; }
+    };
+    auto stash = [&](const int s, const int par) __attribute__((always_inline)) {      // slot s -> LDS buffer `par`
+#pragma unroll
+        for (int q = 0; q < Q; ++q) sw[par * T::BUF + slot[q]] = ring[s][q];
+    };
+    double rec[2][REC];
+    auto readback = [&](const int par, double (&o)[REC]) __attribute__((always_inline)) {
+        const double* r = sw + par * T::BUF + grp * RECP;
+#pragma unroll
+        for (int c = 0; c < REC; ++c) o[c] = r[c];
+    };
+    // prologue: steps 0 .. D+1 fetched; 0 and 1 in LDS; record 0 read back
+#pragma unroll
+    for (int s = 0; s < D; ++s) fetch(s);
+    stash(0, 0); fetch(0);                                                             // slot 0 now holds step D
+    stash(1, 1); fetch(1);                                                             // slot 1 now holds step D + 1
+    __builtin_amdgcn_wave_barrier();
+    readback(0, rec[0]);
+    double cost = 0.0;
+    int next_ck = CKPT ? a.ck : 0;
+    TrigCarry<S> trig;                                                                 // as in closed_loop_range: same pairs, same bits
+    trig.seed(x);
+    int next_seed = a.ck;
+    // step t: record t is in rec[t & 1]; LDS holds t + 1 (buffer (t + 1) & 1) and, once this step has stashed it, t + 2
+    // (buffer t & 1, whose record t was read back during step t - 1); the ring holds t + 2 .. t + D + 1
+    auto one_step = [&](const int t, const int e) __attribute__((always_inline)) {     // e = t mod D (compile time)
+        const int par = e & 1;
+        readback(par ^ 1, rec[par ^ 1]);                                               // record t + 1, for the next step
+        __builtin_amdgcn_wave_barrier();
+        stash((e + 2) % D, par);                                                       // record t + 2 over record t
+        fetch((e + 2) % D);                                                            // step t + 2 + D
+        __builtin_amdgcn_wave_barrier();
+        const double (&r)[REC] = rec[par];
+        if constexpr (CKPT) {
+            if (t == next_ck) {                                                        // state entering segment t / ck
+                if (valid) {
+                    double* c = ckp + (size_t)(t / a.ck) * n * TILE;
+#pragma unroll
+                    for (int i = 0; i < n; ++i) c[(size_t)i * TILE] = x[i];
+                }
+                next_ck += a.ck;
+            }
+        }
+        double u[m], xn[n];
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+            const double ff = alpha * r[T::ok + j];                                    // :146
+            double fb = 0.0;                                                           // :147
+#pragma unroll
+            for (int i = 0; i < n; ++i) fb = __builtin_fma(r[T::oK + j * n + i], x[i] - r[T::oX + i], fb);
+            u[j] = (r[T::oU + j] + fb) + ff;                                           // :148
+        }
+        cost = cost + stage_input_cost<m>(a, u, Rk);
+        if constexpr (S::n_ang > 0) {
+            S::f_sc(x, u, a.dt, p, trig.sc, xn);                                       // :151
+            const bool reseed = t + 1 == next_seed;
+            if (reseed) next_seed += a.ck;
+            trig.advance(x, xn, reseed, !valid || cost > kill_at);
+        } else {
+            S::f(x, u, a.dt, p, xn);                                                   // :151
+        }
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = xn[i];
+    };
+    int t = 0;
+    for (; t + D <= a.N; t += D) {
+#pragma unroll
+        for (int e = 0; e < D; ++e) one_step(t + e, e);
+    }
+#pragma unroll
+    for (int e = 0; e + 1 < D; ++e)
+        if (t + e < a.N) one_step(t + e, e);
+    return cost;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_linesearch: ilqr.py:180-202.  W adjacent lanes evaluate W consecutive trials alpha_j of one problem
 // (64/W problems per wave); the accepted trial is the FIRST j whose Armijo ratio passes (:193), found with a
 // ballot over the lane group -- not the lowest cost.  Rounds of W trials repeat until accepted or exhausted.
@@ -467,6 +610,25 @@ __global__ void __launch_bounds__(W == 64 ? 512 : 256, ls_waves_per_simd<S>()) k
         c = c + terminal_cost<n>(x, target, QT);
         const double cost_difference = cur_cost - c;                               // :191
         const double expected = alpha * dg + (alpha * alpha) * dh;                 // :192
+        okj = valid && (cost_difference / expected) > a.armijo_thr;                // :193 (NaN -> false)
+        if (!valid) c = __builtin_nan("");
+    } else if constexpr (Gather<S, W>::use && !TRACK) {
+        // small records at narrow widths: the wave fetches its 64 / W records cooperatively (closed_loop_gather); lanes
+        // without a trial compute on and are ignored
+        __shared__ double sh[(W == 64 ? 8 : 4) * Gather<S, W>::WAVE_DOUBLES];
+        double* sw = sh + (threadIdx.x >> 6) * Gather<S, W>::WAVE_DOUBLES;
+        const long long b_duty = __shfl(b, (lane % G) * W);
+        const double alpha = a.alphas[j < a.n_trials ? j : 0];
+        double x[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = x0[i];
+        double* ckp = CKPT ? a.CKPT + (size_t)b * a.n_seg * n * TILE + j : nullptr;
+        const double expected = alpha * dg + (alpha * alpha) * dh;                 // :192
+        const bool provable = a.cost_monotone != 0 && expected > 0.0 && a.armijo_thr >= 0.0;   // see the register path below
+        c = closed_loop_gather<S, W, CKPT>(a, sw, lane, grp, b_duty, ckp, valid, x, p, Rk, alpha,
+                                           provable ? cur_cost : __builtin_inf());
+        c = c + terminal_cost<n>(x, target, QT);
+        const double cost_difference = cur_cost - c;                               // :191
         okj = valid && (cost_difference / expected) > a.armijo_thr;                // :193 (NaN -> false)
         if (!valid) c = __builtin_nan("");
     } else if (valid) {
