@@ -294,7 +294,12 @@ def kernel_table(ws, cfg, prof, steps):
                 ('linearize', 0, 0, 1), ('rollout', 0, 0, 1)]
         # the device-side counters accumulate over one solve (reset by solve()): scale to the timed steps
         rows = [(k_, b_ * steps, f_ * steps, l_) for k_, b_, f_, l_ in rows]
-        extra = dict(status=status, iters=iters, trace=trace, ref_trials=ref_trials, ran_ls=ran_ls)
+        # trials the scheme evaluated: a search takes part in rounds until the cumulative width covers what it needed (every
+        # lane of a participating group computes, also those beyond the last trial of the schedule)
+        cum = np.cumsum(info['ls_widths'])
+        need = np.where(accj >= 0, accj + 1, info['n_trials'])
+        eval_trials = cum[np.searchsorted(cum, need)] * ran_ls
+        extra = dict(status=status, iters=iters, trace=trace, ref_trials=ref_trials, ran_ls=ran_ls, eval_trials=eval_trials)
     kern = {}
     for name, bytes_, flops_, launches_per_pass in rows:
         ms, passes = prof[name]
@@ -324,6 +329,47 @@ def roofline_of(kern):
              algorithmic_bytes_per_launch_GB=round(dk['bytes_per_launch'] / 1e9, 4),
              algorithmic_gflop_per_launch=round(dk['flops_per_launch'] / 1e9, 4))
     return r, dominant
+
+
+def pmc_for(name, cfg, B, info):
+    """The committed rocprofv3 PMC summary of this configuration (profiles/pmc_traffic_<name>.json, written by
+    tools/collect_profiles.sh), or None unless it was taken on this very configuration AND on these very kernel sources."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic_%s.json' % name)))
+        c = pmc['config']
+        same = (c['system'], c['batch'], c['n_timesteps'], c['pipeline'], list(c['ls_widths'])) == \
+               (cfg['system'], B, cfg['N'], info['pipeline'], list(info['ls_widths']))
+        return pmc if same and pmc.get('source_hash') == source_hash() else None
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
+def add_pmc(roofline, dominant, pmc, extra, work, cfg):
+    """roofline.traffic (HBM bytes per launch of the dominant kernel, PMC) and roofline.factors: the three factors the
+    FP64 fraction of a line search is the product of -- VALU-busy share of SIMD cycles (PMC), trials the reference needs /
+    trials the scheme evaluates (this run's device trace), credited flops / peak flops of the issue slots spent (the
+    kernel's VALU instructions per trial step, PMC, against 2 flops per lane and slot)."""
+    if pmc is None:
+        return
+    k = pmc['kernels'].get('k_' + dominant)
+    if not k:
+        return
+    roofline['traffic'] = round(k['hbm_bytes_per_launch'] / 1e9, 3)
+    roofline['traffic_unit'] = ('GB per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic_%s.json, kernel sources %s)'
+                                % (pmc['config'].get('name', 'c2'), pmc['source_hash']))
+    if dominant == 'linesearch' and 'eval_trials' in extra and 'valu_busy_frac_of_simd_cycles' in k:
+        ev, need = float(extra['eval_trials'].sum()), float(extra['ref_trials'].sum())
+        # VALU instructions per evaluated trial step: instructions per launch x launches per solve / (lanes-worth of trials x N)
+        insts = k.get('SQ_INSTS_VALU', 0.0) * k['launches'] * 64.0 / max(ev * cfg['N'], 1.0)
+        f = dict(valu_busy=round(k['valu_busy_frac_of_simd_cycles'], 4), trials_needed_over_evaluated=round(need / max(ev, 1.0), 4),
+                 valu_insts_per_trial_step=round(insts, 1),
+                 credited_flops_over_issue_slots=round(work['fwd_flops'] / (2.0 * insts), 4) if insts else None,
+                 trials_needed=need, trials_evaluated=ev)
+        if insts:
+            f['product'] = round(f['valu_busy'] * f['trials_needed_over_evaluated'] * f['credited_flops_over_issue_slots'], 4)
+        f['note'] = ('frac ~ valu_busy x needed/evaluated x credited/slots x (clock under load / 2.4 GHz); valu_busy and the '
+                     'instruction count come from the PMC passes of one solve, the trial counts from this run')
+        roofline['factors'] = f
 
 
 def run_steps(ws, cfg, steps, warmup, after_step=None, barrier=None):
@@ -369,6 +415,7 @@ def extra_config(name, args):
     ws.profile(False)
     kern, info, extra = kernel_table(ws, cfg, prof, steps)
     roof, dominant = roofline_of(kern)
+    add_pmc(roof, dominant, pmc_for(name, cfg, B, info), extra, per_step_work(ws.n, ws.m, *SYSTEM_OPS[cfg['system']]), cfg)
     out = {'workload': '%s, B=%d on one GPU%s' % (cfg['label'], B, '' if cfg['kind'] == 'ltvlqr' else ', %d iterations' % cfg['n_iterations']),
            'value': round(B * steps / elapsed, 1),
            'unit': {'ltvlqr': 'gain schedules/s', 'mpc': 'solve_ilqr calls/s'}.get(cfg['kind'], 'solves/s'),
@@ -381,8 +428,53 @@ def extra_config(name, args):
         st = extra['status']
         out['exit_status_counts'] = {n_: int((st == s).sum()) for s, n_ in ((0, 'max_iter'), (1, 'optimal'), (2, 'low_learning_rate'), (3, 'numerical'))}
         out['mean_ref_trials_per_linesearch'] = round(float(extra['ref_trials'].sum()) / max(int(extra['ran_ls'].sum()), 1), 2)
+        if 'eval_trials' in extra:
+            out['trials_evaluated_over_needed'] = round(float(extra['eval_trials'].sum()) / max(float(extra['ref_trials'].sum()), 1.0), 3)
     ws.close()
     return out
+
+
+def api_config(name):
+    """The drop-in boundary itself under the clock: ilqr_amd.ilqr(...).solve() with host numpy in and host numpy out (workspace
+    creation, H2D, solve, D2H, destruction).  c1 = BASELINE configs[0], the pendulum example, one problem
+    (example_pendulum_swingup.py:14-47); c2_api = the headline batch through the class (example_acrobot_swingup.py:51-54 with a
+    leading batch axis)."""
+    import contextlib
+    import io
+    import ilqr_amd
+    if name == 'c1':
+        g = golden('pendulum_solve')
+        fab = ilqr_amd.symbolic_dynamics_pendulum()
+        ts = []
+        for _ in range(21):
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                s = ilqr_amd.ilqr(g['init'], g['target'], g['guess'], float(g['dt']), float(g['start']), float(g['end']), *fab, g['Qk'],
+                                  g['Rk'], g['QT'], g['params'], int(g['n_iterations']))
+                out = s.solve()
+            ts.append(time.perf_counter() - t0)
+        ts = ts[1:]
+        return {'workload': 'pendulum swing-up example (BASELINE configs[0]): one problem, n=2 m=1 N=%d, ilqr(...).solve() end to end through '
+                            'the drop-in class, host arrays in and out' % g['guess'].shape[0],
+                'value': round(1.0 / float(np.median(ts)), 2), 'unit': 'solves/s', 'ms_per_solve_median': round(1e3 * float(np.median(ts)), 3),
+                'ms_per_solve_min': round(1e3 * min(ts), 3), 'runs': len(ts), 'iterations': int(s.iterations_),
+                'cost_rel_err_vs_reference': float(abs(out[4] - g['cost']) / abs(g['cost'])),
+                'reference_python_seconds': 1.11, 'reference_note': 'BASELINE.md: the reference python, one core of the build container'}
+    cfg = acrobot_c2(DEFAULT_BATCH['c2'], 0)
+    fab = ilqr_amd.symbolic_dynamics_acrobot()
+    ts = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        s = ilqr_amd.ilqr(cfg['init'], cfg['target'], cfg['guess'], cfg['dt'], 0, 3, *fab, cfg['Qk'], cfg['Rk'], cfg['QT'], cfg['params'], 10)
+        out = s.solve()
+        ts.append(time.perf_counter() - t0)
+    ts = ts[1:]
+    nbytes = sum(o.nbytes for o in out[:4]) + cfg['guess'].nbytes + cfg['init'].nbytes
+    B = DEFAULT_BATCH['c2']
+    return {'workload': 'the headline batch through the drop-in class: ilqr(init (B,4), ..., guess (B,N,1)).solve(), B=%d, host numpy in, '
+                        'host numpy out (states, inputs, k, K, cost), 10 iterations' % B,
+            'value': round(B / float(np.median(ts)), 1), 'unit': 'solves/s', 'ms_per_step': round(1e3 * float(np.median(ts)), 2),
+            'ms_min': round(1e3 * min(ts), 2), 'runs': len(ts), 'bytes_across_the_boundary_GB': round(nbytes / 1e9, 3)}
 
 
 def main():
@@ -479,10 +571,14 @@ def main():
         gathered['rec'] = all_gather_summary(rec, total, device=torch.device('cuda', local_rank) if args.backend == 'nccl' else None)
 
     elapsed = run_steps(ws, cfg, args.steps, args.warmup, after_step=after_step, barrier=barrier)
+    per_rank_ms = None
     if dist is not None:
+        # every rank's own wall time of the timed region (all-gather, so a straggler shows in rank 0's line); value uses the MAX
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        ts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(ts, t)
+        per_rank_ms = [round(1e3 * float(x.item()) / args.steps, 3) for x in ts]
+        elapsed = max(float(x.item()) for x in ts)
     prof = ws.profile_read()
     ws.profile(False)
 
@@ -494,17 +590,10 @@ def main():
     kern, info, extra = kernel_table(ws, cfg, prof, args.steps)
     roofline, dominant = roofline_of(kern)
     W = info['n_alpha_parallel']
-    # HBM traffic of that kernel from the committed rocprofv3 PMC passes (collected separately: counters cannot be read
-    # from inside this process), only when they were taken on this very configuration AND on these very kernel sources
-    try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-        c = pmc['config']
-        same_cfg = (c['system'], c['batch'], c['n_timesteps'], c['n_alpha_parallel'], c['pipeline']) == (cfg['system'], B, N, W, info['pipeline'])
-        if same_cfg and cfg['kind'] == 'solve' and args.iterations == 10 and pmc.get('source_hash') == source_hash():
-            roofline['traffic'] = round(pmc['kernels']['k_' + dominant]['hbm_bytes_per_launch'] / 1e9, 3)
-            roofline['traffic_unit'] = 'GB per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json, kernel sources %s)' % pmc['source_hash']
-    except (OSError, KeyError, ValueError):
-        pass
+    # HBM traffic and VALU-busy of that kernel from the committed rocprofv3 PMC passes (collected separately: counters cannot
+    # be read from inside this process), only when they were taken on this very configuration AND on these very kernel sources
+    if cfg['kind'] == 'solve' and args.iterations == 10 and not strong:
+        add_pmc(roofline, dominant, pmc_for(args.config, cfg, B, info), extra, per_step_work(ws.n, ws.m, *SYSTEM_OPS[cfg['system']]), cfg)
     roofline.update(n_alpha_parallel=W, ls_widths=info['ls_widths'],
                     note='peak = FP64 vector rate (= FP64 MFMA rate on MI355X); MFMA itself is not used, see DESIGN.md')
 
@@ -516,7 +605,7 @@ def main():
         'value': round(value, 2), 'unit': unit,
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
         'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': '%s, %s%s' % (cfg['label'], ('ONE batch of %d problems split over %d GPU(s)' % (total, world)) if strong
+        'config': {'baseline_config': args.config, 'workload': '%s, %s%s' % (cfg['label'], ('ONE batch of %d problems split over %d GPU(s)' % (total, world)) if strong
                                              else 'B=%d problems per GPU' % B,
                                              ', %d iterations, reference line search + stop tests active' % cfg['n_iterations'] if cfg['kind'] != 'ltvlqr' else ''),
                    'problems_per_gpu': B, 'problems_total': total, 'n_timesteps': N, 'n_alpha_parallel': W, 'pipeline': info['pipeline'],
@@ -525,9 +614,15 @@ def main():
         'roofline': roofline,
         'kernels': {k_: {kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in kv.items()} for k_, kv in kern.items()},
     }
+    if per_rank_ms is not None:
+        out['per_rank_ms_per_step'] = per_rank_ms
     if dist is not None and 'rec' in gathered:
-        out['ranks_seen'] = world
-        out['gathered_records'] = int(gathered['rec'].shape[0])
+        # a rank whose shard arrived: every problem of its slice carries a backward-pass count >= 1 (a record that never
+        # arrived is the all-gather buffer's zeros)
+        rec = gathered['rec']
+        out['ranks_seen'] = sum(1 for r in range(world) if (lambda lo, hi: hi > lo and bool(np.all(rec[lo:hi, 1] >= 1)))(*shard_range(total, r, world)))
+        out['ranks_expected'] = world
+        out['gathered_records'] = int(rec.shape[0])
         out['gathered_status_counts'] = {_lib.STATUS_NAMES[s]: int((gathered['rec'][:, 2] == s).sum()) for s in range(4)}
     if cfg['kind'] in ('solve', 'mpc'):
         status, trace = extra['status'], extra['trace']
@@ -539,6 +634,7 @@ def main():
         out['ms_per_bwd_fwd_pass'] = round((1e3 * elapsed / args.steps - once_ms) / max(cfg['n_iterations'], 1), 4)
         out['exit_status_counts'] = {_lib.STATUS_NAMES[s]: int((status == s).sum()) for s in range(4)}
         out['mean_ref_trials_per_linesearch'] = round(float(extra['ref_trials'].sum()) / max(int(extra['ran_ls'].sum()), 1), 2)
+        out['trials_evaluated_over_needed'] = round(float(extra['eval_trials'].sum()) / max(float(extra['ref_trials'].sum()), 1.0), 3)
         # sanity: problem 0 is the reference's own example; compare its first iterations with the committed golden trace
         if args.config == 'c2' and not strong:
             g = golden('acrobot_solve')
@@ -566,6 +662,13 @@ def main():
             try:
                 out['extra_configs'][name] = extra_config(name, args)
             except Exception as e:                             # an extra block must never cost the headline line
+                out['extra_configs'][name] = {'error': repr(e)[:300]}
+        for name in ('c1', 'c2_api'):
+            try:
+                out['extra_configs'][name] = api_config(name)
+                if name == 'c2_api':
+                    out['extra_configs'][name]['resident_ms_per_step'] = out['ms_per_step']
+            except Exception as e:
                 out['extra_configs'][name] = {'error': repr(e)[:300]}
     json_out.write(json.dumps(out) + '\n')
     json_out.flush()

@@ -21,6 +21,7 @@
 // (__builtin_fma in the small dense products), never inside the generated dynamics.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -147,9 +148,6 @@ constexpr int CKPT_INTERVAL = ILQR_CKPT_INTERVAL;   // time steps between line-s
 
 }  // namespace
 
-#ifndef ILQR_OVERLAP_GEOMETRIC
-#define ILQR_OVERLAP_GEOMETRIC 0
-#endif
 #ifndef ILQR_OVERLAP_CHUNKS
 #define ILQR_OVERLAP_CHUNKS 10
 #endif
@@ -168,8 +166,6 @@ struct ilqr_ws {
     long long sub_tile0[5];
     double *XB, *CKPT, *LIN;
     int split, grp, quad, overlap, n_chunks, ck, n_seg, n_lin;
-    hipStream_t pipe_stream;                 // overlap: the Riccati chunks run here, the accept chunks on `stream`
-    hipEvent_t pipe_ev[OVERLAP_CHUNKS], pipe_done;
     double* VST;
     double *X, *U, *G, *KFB, *KFF, *XO, *UO, *INIT, *TARGET, *PARAMS, *WTS, *alphas, *alpha_pp, *cost, *new_cost, *dJ, *trace;
     double *XD, *UD;                         // tracking cost (ilqr_desc.tracking): per-step targets of the horizon window
@@ -331,6 +327,102 @@ int ensure_forward_out(ilqr_ws* ws)
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Host <-> device copies of the one-shot entry points.  The caller's arrays are ordinary pageable memory (numpy): a plain
+// hipMemcpy to or from them runs at 8-10 GB/s (measured: 1 GB of results of the 4096-problem headline batch took 107 ms
+// next to a 48 ms solve).  Large copies therefore go through a small pool of PINNED bounce buffers kept for the life of the
+// process (HOST_COPY_CHUNK bytes each, at most HOST_COPY_WORKERS per call): every worker thread owns one buffer and one
+// stream and alternates a DMA of its chunk with the memcpy between the buffer and the caller's pages, so the DMAs of some
+// workers run under the memcpys (and first-touch page faults) of the others.
+// ------------------------------------------------------------------------------------------------
+constexpr size_t HOST_COPY_CHUNK = (size_t)8 << 20;
+constexpr int HOST_COPY_WORKERS = 8;
+constexpr size_t HOST_COPY_DIRECT_BELOW = (size_t)4 << 20;     // smaller copies: one plain hipMemcpy
+struct PinnedSlot { void* host; hipStream_t st; int device; bool busy; };
+std::mutex g_pinned_mutex;
+std::vector<PinnedSlot> g_pinned;
+
+int pinned_acquire(int device, int* index)
+{
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    for (size_t i = 0; i < g_pinned.size(); ++i)
+        if (!g_pinned[i].busy && g_pinned[i].device == device) { g_pinned[i].busy = true; *index = (int)i; return 0; }
+    PinnedSlot sl{nullptr, nullptr, device, true};
+    HIPCHK(hipHostMalloc(&sl.host, HOST_COPY_CHUNK, hipHostMallocDefault));
+    hipError_t e = hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking);
+    if (e != hipSuccess) { (void)hipHostFree(sl.host); return fail(-100 - (int)e, "hipStreamCreateWithFlags: %s", hipGetErrorString(e)); }
+    g_pinned.push_back(sl);
+    *index = (int)g_pinned.size() - 1;
+    return 0;
+}
+PinnedSlot g_pinned_at(int index)
+{
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    return g_pinned[index];
+}
+void pinned_release(int index)
+{
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    g_pinned[index].busy = false;
+}
+
+struct CopySeg { char* dev; char* host; size_t bytes; };
+// every segment copied (to_device: host -> device); the device side must be idle / complete on entry (the caller has
+// synchronised the stream that produced or will consume it) and the copies are complete on return
+int host_copy(int device, const std::vector<CopySeg>& segs, bool to_device)
+{
+    struct Chunk { char* dev; char* host; size_t bytes; };
+    std::vector<Chunk> chunks;
+    for (const CopySeg& sg : segs) {
+        if (sg.bytes == 0) continue;
+        if (sg.bytes < HOST_COPY_DIRECT_BELOW) {
+            HIPCHK(to_device ? hipMemcpy(sg.dev, sg.host, sg.bytes, hipMemcpyHostToDevice) : hipMemcpy(sg.host, sg.dev, sg.bytes, hipMemcpyDeviceToHost));
+            continue;
+        }
+        for (size_t off = 0; off < sg.bytes; off += HOST_COPY_CHUNK)
+            chunks.push_back({sg.dev + off, sg.host + off, sg.bytes - off < HOST_COPY_CHUNK ? sg.bytes - off : HOST_COPY_CHUNK});
+    }
+    if (chunks.empty()) return 0;
+    const int T = (int)chunks.size() < HOST_COPY_WORKERS ? (int)chunks.size() : HOST_COPY_WORKERS;
+    std::vector<int> rcs(T, 0);
+    std::vector<std::string> errs(T);
+    std::atomic<size_t> next{0};
+    auto body = [&](int w) {
+        try {
+            if (hipSetDevice(device) != hipSuccess) { rcs[w] = fail(-100, "hipSetDevice(%d) failed in a copy thread", device); errs[w] = g_err; return; }
+            int slot = -1;
+            if ((rcs[w] = pinned_acquire(device, &slot))) { errs[w] = g_err; return; }
+            const PinnedSlot sl = g_pinned_at(slot);
+            for (size_t c = next.fetch_add(1); c < chunks.size() && !rcs[w]; c = next.fetch_add(1)) {
+                const Chunk& ch = chunks[c];
+                hipError_t e;
+                if (to_device) {
+                    memcpy(sl.host, ch.host, ch.bytes);
+                    e = hipMemcpyAsync(ch.dev, sl.host, ch.bytes, hipMemcpyHostToDevice, sl.st);
+                    if (e == hipSuccess) e = hipStreamSynchronize(sl.st);
+                } else {
+                    e = hipMemcpyAsync(sl.host, ch.dev, ch.bytes, hipMemcpyDeviceToHost, sl.st);
+                    if (e == hipSuccess) e = hipStreamSynchronize(sl.st);
+                    if (e == hipSuccess) memcpy(ch.host, sl.host, ch.bytes);
+                }
+                if (e != hipSuccess) { rcs[w] = fail(-100 - (int)e, "host copy: %s", hipGetErrorString(e)); errs[w] = g_err; }
+            }
+            pinned_release(slot);
+        } catch (...) {
+            rcs[w] = -1; errs[w] = "exception in a copy thread";
+        }
+    };
+    std::vector<std::thread> threads;
+    try {
+        for (int w = 1; w < T; ++w) threads.emplace_back(body, w);
+    } catch (...) { /* fewer helpers: the calling thread and the ones that started drain the chunk list */ }
+    body(0);
+    for (auto& t : threads) t.join();
+    for (int w = 0; w < T; ++w)
+        if (rcs[w]) return fail(rcs[w], "%s", errs[w].c_str());
+    return 0;
+}
+
 // every per-problem array is [tile][TC][64] on the device and (B,TC) at the boundary
 int do_upload(ilqr_ws* ws, int field, const void* src, bool src_on_device, long long rows)
 {
@@ -357,7 +449,9 @@ int do_upload(ilqr_ws* ws, int field, const void* src, bool src_on_device, long 
     if (!src_on_device) {
         rc = ensure_staging(ws, (size_t)copy_elems * sizeof(double));
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(ws->staging, src, (size_t)copy_elems * sizeof(double), hipMemcpyHostToDevice, ws->stream));
+        // (the staging buffer is free: every earlier use was followed by a stream synchronisation)
+        rc = host_copy(ws->d.device, {{(char*)ws->staging, (char*)const_cast<void*>(src), (size_t)copy_elems * sizeof(double)}}, true);
+        if (rc) return rc;
         dsrc = (const double*)ws->staging;
     }
     {
@@ -372,36 +466,48 @@ int do_upload(ilqr_ws* ws, int field, const void* src, bool src_on_device, long 
     return 0;
 }
 
-int do_download(ilqr_ws* ws, int field, void* dst, bool dst_on_device)
+// Several fields at once: every field is unpacked (tiled -> (B, TC)) into its own slice of the staging buffer, ONE stream
+// synchronisation, then all slices travel together (host_copy).  dst_on_device: unpacked straight into the caller's device
+// buffers, nothing else.
+struct DlItem { int field; void* dst; };
+int do_download_many(ilqr_ws* ws, const DlItem* items, int n_items, bool dst_on_device)
 {
     int rc = set_device(ws);
     if (rc) return rc;
-    int is_int; long long tc; double* dp; int* ip;
-    if (!field_elems(ws, field, &is_int, &tc, &dp, &ip)) return fail(-3, "download: unknown field %d", field);
-    if (field == ILQR_F_TRACE && !ws->want_trace) return fail(-3, "download: workspace was created without a trace");
-    if (!dp && !ip) return fail(-3, "download: field %d not allocated", field);
-    const size_t esz = is_int ? sizeof(int) : sizeof(double);
-    const size_t bytes = (size_t)ws->B * tc * esz;
-    void* ddst = dst;
-    if (!dst_on_device) {
-        rc = ensure_staging(ws, bytes);
-        if (rc) return rc;
-        ddst = ws->staging;
+    struct Plan { int is_int; long long tc; double* dp; int* ip; size_t bytes, off; };
+    if (n_items < 0 || n_items > 8) return fail(-3, "download: at most 8 fields per call");
+    Plan plan[8];
+    size_t total = 0;
+    for (int i = 0; i < n_items; ++i) {
+        Plan& pl = plan[i];
+        const int field = items[i].field;
+        if (!field_elems(ws, field, &pl.is_int, &pl.tc, &pl.dp, &pl.ip)) return fail(-3, "download: unknown field %d", field);
+        if (field == ILQR_F_TRACE && !ws->want_trace) return fail(-3, "download: workspace was created without a trace");
+        if (!pl.dp && !pl.ip) return fail(-3, "download: field %d not allocated", field);
+        pl.bytes = (size_t)ws->B * pl.tc * (pl.is_int ? sizeof(int) : sizeof(double));
+        pl.off = total;
+        total += (pl.bytes + 255) & ~(size_t)255;
     }
-    const long long total = ws->Bpad * tc;
-    const unsigned grid = (unsigned)((total + 255) / 256);
-    if (is_int) {
-        hipLaunchKernelGGL(k_unpack<int>, dim3(grid), dim3(256), 0, ws->stream, ip, (int*)ddst, ws->B, ws->Bpad, tc);
-    } else {
-        hipLaunchKernelGGL(k_unpack<double>, dim3(grid), dim3(256), 0, ws->stream, dp, (double*)ddst, ws->B, ws->Bpad, tc);
+    if (!dst_on_device && (rc = ensure_staging(ws, total))) return rc;
+    for (int i = 0; i < n_items; ++i) {
+        const Plan& pl = plan[i];
+        void* ddst = dst_on_device ? items[i].dst : (void*)((char*)ws->staging + pl.off);
+        const long long cnt = ws->Bpad * pl.tc;
+        const unsigned grid = (unsigned)((cnt + 255) / 256);
+        if (pl.is_int) hipLaunchKernelGGL(k_unpack<int>, dim3(grid), dim3(256), 0, ws->stream, pl.ip, (int*)ddst, ws->B, ws->Bpad, pl.tc);
+        else hipLaunchKernelGGL(k_unpack<double>, dim3(grid), dim3(256), 0, ws->stream, pl.dp, (double*)ddst, ws->B, ws->Bpad, pl.tc);
+        if ((rc = check_launch("k_unpack"))) return rc;
     }
-    rc = check_launch("k_unpack");
-    if (rc) return rc;
-    if (!dst_on_device) {
-        HIPCHK(hipMemcpyAsync(dst, ws->staging, bytes, hipMemcpyDeviceToHost, ws->stream));
-        HIPCHK(hipStreamSynchronize(ws->stream));
-    }
-    return 0;
+    if (dst_on_device) return 0;
+    HIPCHK(hipStreamSynchronize(ws->stream));
+    std::vector<CopySeg> segs;
+    for (int i = 0; i < n_items; ++i) segs.push_back({(char*)ws->staging + plan[i].off, (char*)items[i].dst, plan[i].bytes});
+    return host_copy(ws->d.device, segs, false);
+}
+int do_download(ilqr_ws* ws, int field, void* dst, bool dst_on_device)
+{
+    const DlItem it{field, dst};
+    return do_download_many(ws, &it, 1, dst_on_device);
 }
 
 int fill_i32(ilqr_ws* ws, int* p, int v)
@@ -461,10 +567,13 @@ int ws_accept_lin(ilqr_ws* ws, int it, int sub = -1)
     }, sub);
 }
 // accept of iteration `it` and the Riccati recursion of iteration it + 1, overlapped: the accept step is parallel over
-// segments of the horizon, the recursion walks the horizon from its end -- so the accept runs in chunks, last segments
-// first, on the workspace stream, and each chunk of the recursion (k_riccati_quad over the same steps, value function
-// handed on through VST) follows its accept chunk on a second stream while the earlier segments are still being
-// accepted.  Same kernels, same arithmetic, same results; only the first accept chunk is not hidden.
+// segments of the horizon, the recursion walks the horizon from its end -- so the horizon is cut into chunks, last segments
+// first, and launch c runs the accept step of chunk c TOGETHER with the recursion of chunk c + 1 (k_accept_riccati: one
+// grid, the recursion's workgroups first; value function handed from chunk to chunk through VST).  Everything is on the
+// workspace's ONE stream: the recursion of a chunk follows the accept of that chunk by stream order.  (Rounds 1-2 ran the two
+// on two streams joined by events; with a second PROCESS on the same GPU that layout stalled for good in 2 of 41 rehearsals
+// -- DESIGN.md section 5.  The dependency graph was sound; a solve now has no cross-queue dependency at all.)  Same
+// kernels, same arithmetic, same results; only the first accept chunk and the last recursion chunk run alone.
 int ws_accept_riccati_overlapped(ilqr_ws* ws, int it)
 {
     if (!ws) return fail(-1, "null workspace");
@@ -473,45 +582,37 @@ int ws_accept_riccati_overlapped(ilqr_ws* ws, int it)
     KArgs aa = make_args(ws, it), ar = make_args(ws, it + 1);
     if (aa.n_tiles <= 0) return 0;
     ar.piped = 1;
-    hipStream_t A = ws->stream, B = ws->pipe_stream;
+    hipStream_t A = ws->stream;
     return with_system(ws->d.system_id, [&](auto S) {
         using T = decltype(S);
         if constexpr (T::n <= 4) {
+            const int C = ws->n_chunks;
+            auto seg_lo = [&](int c) { return (int)((long long)ws->n_seg * c / C); };
+            const unsigned n_ric = (unsigned)(ar.n_tiles * 4);
             int rc2 = 0;
             {
-                ProfScope pa(ws, KID_ACCEPT, A);
+                ProfScope pa(ws, KID_ACCEPT, A);                       // the exposed part of the accept step: its first chunk
                 hipLaunchKernelGGL(k_save_boundaries, dim3((unsigned)(aa.n_tiles * ws->n_seg)), dim3(64), 0, A, aa, (int)T::n);
-                std::unique_ptr<ProfScope> pb;
-                const int C = ws->n_chunks;
-                for (int c = C - 1; c >= 0 && !rc2; --c) {
-#if ILQR_OVERLAP_GEOMETRIC
-                    // chunk sizes growing from the end of the horizon (the first accept chunk is the exposed one, the later
-                    // ones fill the chip better): boundary of chunk c = n_seg * (1 - ((C - c) / C)^2).  Measured and left
-                    // off: the accept finishes sooner but the recursion, which is the critical path, is slowed more while
-                    // it lasts (63.4 vs 62.1 ms per solve with 10 chunks; 16 and 24 uniform chunks: 65.5 and 73.0)
-                    auto bound = [&](int cc) { const double f = (double)(C - cc) / C; return (int)(ws->n_seg * (1.0 - f * f) + 0.5); };
-                    const int s_lo = bound(c), s_hi = c + 1 == C ? ws->n_seg : bound(c + 1);
-#else
-                    const int s_lo = (int)((long long)ws->n_seg * c / C), s_hi = (int)((long long)ws->n_seg * (c + 1) / C);
-#endif
-                    if (s_hi <= s_lo) continue;
-                    aa.seg_lo = s_lo; aa.seg_cnt = s_hi - s_lo;
-                    hipLaunchKernelGGL(k_accept_lin<T>, dim3((unsigned)(aa.n_tiles * aa.seg_cnt)), dim3(64), 0, A, aa);
-                    if ((rc2 = check_launch("k_accept_lin"))) break;
-                    if (hipEventRecord(ws->pipe_ev[c], A) != hipSuccess || hipStreamWaitEvent(B, ws->pipe_ev[c], 0) != hipSuccess) {
-                        rc2 = fail(-100, "overlap: event record / wait failed");
-                        break;
-                    }
-                    if (!pb) pb.reset(new ProfScope(ws, KID_BACKWARD, B));
-                    ar.t_lo = s_lo * ws->ck;
-                    ar.t_hi = s_hi * ws->ck < ws->N ? s_hi * ws->ck : ws->N;
-                    hipLaunchKernelGGL((k_riccati_quad<T, true>), dim3((unsigned)(ar.n_tiles * 4)), dim3(64), 0, B, ar);
-                    rc2 = check_launch("k_riccati_quad");
+                aa.seg_lo = seg_lo(C - 1); aa.seg_cnt = ws->n_seg - aa.seg_lo;
+                hipLaunchKernelGGL(k_accept_lin<T>, dim3((unsigned)(aa.n_tiles * aa.seg_cnt)), dim3(64), 0, A, aa);
+                if ((rc2 = check_launch("k_accept_lin"))) return rc2;
+            }
+            ProfScope pb(ws, KID_BACKWARD, A);                         // recursion chunks, each next to the accept chunk below it
+            for (int c = C - 1; c >= 0; --c) {
+                ar.t_lo = seg_lo(c) * ws->ck;
+                ar.t_hi = c + 1 == C ? ws->N : seg_lo(c + 1) * ws->ck;
+                if (c > 0) {
+                    aa.seg_lo = seg_lo(c - 1); aa.seg_cnt = seg_lo(c) - aa.seg_lo;
                 }
-            }   // the accept scope closes on A here; pb closed on B when it went out of scope above
-            if (hipEventRecord(ws->pipe_done, B) != hipSuccess || hipStreamWaitEvent(A, ws->pipe_done, 0) != hipSuccess)
-                return fail(-100, "overlap: joining the streams failed");
-            return rc2;
+                if (c > 0 && aa.seg_cnt > 0) {
+                    hipLaunchKernelGGL(k_accept_riccati<T>, dim3(n_ric + (unsigned)(aa.n_tiles * aa.seg_cnt)), dim3(64), 0, A, aa, ar, n_ric);
+                    if ((rc2 = check_launch("k_accept_riccati"))) return rc2;
+                } else {
+                    hipLaunchKernelGGL((k_riccati_quad<T, true>), dim3(n_ric), dim3(64), 0, A, ar);
+                    if ((rc2 = check_launch("k_riccati_quad"))) return rc2;
+                }
+            }
+            return 0;
         } else {
             return fail(-1, "overlap needs the four-lane Riccati kernel (n <= 4)");
         }
@@ -945,20 +1046,6 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
             WSCHK(hipEventCreateWithFlags(&ws->sub_done[sb], hipEventDisableTiming));
         }
     }
-    if (ws->overlap) {
-        // A stream of its own priority class: HIP deals streams of one priority round-robin over a few hardware queues
-        // (4 per process here), so with other streams alive in the process (torch, RCCL) `stream` and a plain second
-        // stream can land on the SAME queue and the overlapped pair runs back to back (measured under
-        // torch.distributed: recursion 1.6 -> 2.6 ms, 61 -> 72 ms per solve).  High-priority streams have their own
-        // queues -- and the recursion is the critical path of the pair.
-        int prio_least = 0, prio_greatest = 0;
-        WSCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        const char* pe = getenv("ILQR_PIPE_PRIORITY");                      // development aid: 0 = a plain second stream
-        if (pe && atoi(pe) == 0) prio_greatest = prio_least;
-        WSCHK(hipStreamCreateWithPriority(&ws->pipe_stream, hipStreamDefault, prio_greatest));
-        for (int c = 0; c < OVERLAP_CHUNKS; ++c) WSCHK(hipEventCreateWithFlags(&ws->pipe_ev[c], hipEventDisableTiming));
-        WSCHK(hipEventCreateWithFlags(&ws->pipe_done, hipEventDisableTiming));
-    }
     WSCHK(hipMemcpy(ws->alphas, alphas, sizeof(alphas), hipMemcpyHostToDevice));
     WSCHK(hipMemsetAsync(ws->WTS, 0, (2 * n * n + m * m) * 8, ws->stream));
     WSCHK(hipMemsetAsync(ws->dJ, 0, 3 * Bp * 8, ws->stream));
@@ -991,9 +1078,6 @@ int ilqr_ws_destroy(ilqr_ws* ws)
     (void)hipSetDevice(ws->d.device);
     if (ws->stream) (void)hipStreamSynchronize(ws->stream);
     for (auto& ev : ws->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    if (ws->pipe_stream) { (void)hipStreamSynchronize(ws->pipe_stream); (void)hipStreamDestroy(ws->pipe_stream); }
-    for (int c = 0; c < OVERLAP_CHUNKS; ++c) if (ws->pipe_ev[c]) (void)hipEventDestroy(ws->pipe_ev[c]);
-    if (ws->pipe_done) (void)hipEventDestroy(ws->pipe_done);
     void* ptrs[] = {ws->XD, ws->UD, ws->VST, ws->XB, ws->CKPT, ws->LIN, ws->X, ws->U, ws->G, ws->KFB, ws->KFF, ws->XO, ws->UO, ws->INIT, ws->TARGET, ws->PARAMS, ws->WTS, ws->alphas,
                     ws->alpha_pp, ws->cost, ws->new_cost, ws->dJ, ws->trace, ws->active, ws->iters, ws->status, ws->acc_j,
                     ws->ls_rounds, ws->accepts, ws->ls_list, ws->ls_count, ws->staging};
@@ -1385,14 +1469,19 @@ int ilqr_solve_batched(const ilqr_desc* d, const double* init_state, const doubl
     TRY(ilqr_ws_upload(ws, ILQR_F_PARAMS, params, 0));
     TRY(ilqr_ws_upload(ws, ILQR_F_GUESS, guess, 0));
     TRY(ilqr_ws_solve(ws));
-    if (states) TRY(ilqr_ws_download(ws, ILQR_F_STATES, states));
-    if (inputs) TRY(ilqr_ws_download(ws, ILQR_F_INPUTS, inputs));
-    if (k) TRY(ilqr_ws_download(ws, ILQR_F_KFF, k));
-    if (K) TRY(ilqr_ws_download(ws, ILQR_F_KFB, K));
-    if (cost) TRY(ilqr_ws_download(ws, ILQR_F_COST, cost));
-    if (iters) TRY(ilqr_ws_download(ws, ILQR_F_ITERS, iters));
-    if (status) TRY(ilqr_ws_download(ws, ILQR_F_STATUS, status));
-    if (trace && ws->want_trace) TRY(ilqr_ws_download(ws, ILQR_F_TRACE, trace));
+    {
+        DlItem items[8];
+        int cnt = 0;
+        if (states) items[cnt++] = {ILQR_F_STATES, states};
+        if (inputs) items[cnt++] = {ILQR_F_INPUTS, inputs};
+        if (k) items[cnt++] = {ILQR_F_KFF, k};
+        if (K) items[cnt++] = {ILQR_F_KFB, K};
+        if (cost) items[cnt++] = {ILQR_F_COST, cost};
+        if (iters) items[cnt++] = {ILQR_F_ITERS, iters};
+        if (status) items[cnt++] = {ILQR_F_STATUS, status};
+        if (trace && ws->want_trace) items[cnt++] = {ILQR_F_TRACE, trace};
+        TRY(do_download_many(ws, items, cnt, false));
+    }
     return ilqr_ws_destroy(ws);
 }
 

@@ -543,16 +543,18 @@ __device__ __forceinline__ double dot_dense(const double (&a)[CNT], const double
 #ifndef RICCATI_QUAD_PREFETCH_DEEP
 #define RICCATI_QUAD_PREFETCH_DEEP 10
 #endif
-template <class S, bool DEEP = false>
-__global__ void __launch_bounds__(64) k_riccati_quad(const KArgs a)
+// (the body is a device function of the workgroup index so that k_accept_riccati -- kernels_forward.h -- can run it next to
+// the accept step's workgroups in ONE launch)
+template <class S, bool DEEP>
+__device__ __forceinline__ void riccati_quad_body(const KArgs& a, const unsigned bid)
 {
     constexpr int n = S::n, m = S::m, NL = Lin<S>::n_lin;
     static_assert(n <= 4, "k_riccati_quad: one lane per column, four lanes per problem");
-    const long long tile = a.tile0 + (blockIdx.x >> 2);
+    const long long tile = a.tile0 + (bid >> 2);
     const int lane = threadIdx.x;
     const int c = (lane & 3) < n ? (lane & 3) : n - 1;                                 // lanes beyond n shadow the last column
     const bool owner = (lane & 3) < n;
-    const int bl = ((blockIdx.x & 3) << 4) + (lane >> 2);                              // problem within the tile
+    const int bl = ((bid & 3) << 4) + (lane >> 2);                                     // problem within the tile
     const long long b = tile * TILE + bl;
     // overlapped with the accept step of the previous iteration (a.piped): that step's seg-0 block has not yet retired the
     // problems whose search ended the solve (ilqr.py:204), so they are masked here the way their cleared `active` would
@@ -790,6 +792,11 @@ __global__ void __launch_bounds__(64) k_riccati_quad(const KArgs a)
         return;
     }
     if (act && (lane & 3) == 0) backward_epilogue(a, tile, bl, b, ecr, ecr_g, ecr_h, ok);
+}
+template <class S, bool DEEP = false>
+__global__ void __launch_bounds__(64) k_riccati_quad(const KArgs a)
+{
+    riccati_quad_body<S, DEEP>(a, blockIdx.x);
 }
 
 // LTV = true: the ltvlqr recursion (ltvlqr.py:14-27) on the same lane mapping -- no V_x, k or expected reductions, the

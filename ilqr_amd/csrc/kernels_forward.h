@@ -797,11 +797,11 @@ __global__ void __launch_bounds__(64) k_mpc_shift(const KArgs a, const int n, co
 //   k_riccati    : the horizon-sequential part of backwards_pass (:99-125) reading LIN instead of calling A(), B().
 // ------------------------------------------------------------------------------------------------
 template <class S>
-__global__ void __launch_bounds__(64) k_accept_lin(const KArgs a)
+__device__ __forceinline__ void accept_lin_body(const KArgs& a, const unsigned bid)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
-    const long long tile = a.tile0 + blockIdx.x / a.seg_cnt;                           // grid = tiles x seg_cnt
-    const int seg = a.seg_lo + (int)(blockIdx.x % a.seg_cnt);
+    const long long tile = a.tile0 + bid / a.seg_cnt;                                  // grid = tiles x seg_cnt
+    const int seg = a.seg_lo + (int)(bid % a.seg_cnt);
     const int lane = threadIdx.x;
     const long long b = tile * TILE + lane;
     const bool act = a.active[b] != 0;
@@ -843,6 +843,25 @@ __global__ void __launch_bounds__(64) k_accept_lin(const KArgs a)
                 tr[4 * TILE] = (double)accj; tr[5 * TILE] = nc;
             }
         }
+    }
+}
+
+template <class S>
+__global__ void __launch_bounds__(64) k_accept_lin(const KArgs a)
+{
+    accept_lin_body<S>(a, blockIdx.x);
+}
+// The accept step of iteration i over the segments of one chunk of the horizon (workgroups n_ric ...) and the Riccati
+// recursion of iteration i + 1 over the steps of the chunk ABOVE it (workgroups 0 .. n_ric - 1: dispatched first, they are
+// the critical path), in ONE launch.  The recursion's chunk needs the accept step's result for ITS steps -- the previous
+// launch on the same stream -- and the value function of the chunk above it -- the previous launch as well; the two
+// halves of this launch touch disjoint time steps.  Stream order is the only synchronisation: no second stream, no events.
+template <class S>
+__global__ void __launch_bounds__(64) k_accept_riccati(const KArgs aa, const KArgs ar, const unsigned n_ric)
+{
+    if constexpr (S::n <= 4) {
+        if (blockIdx.x < n_ric) riccati_quad_body<S, true>(ar, blockIdx.x);
+        else accept_lin_body<S>(aa, blockIdx.x - n_ric);
     }
 }
 
