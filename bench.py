@@ -249,11 +249,7 @@ def make_workspace(cfg, B, device, args, want_trace=True):
         ws = ilqr_amd.Workspace(cfg['system'], cfg['N'], B, cfg['dt'], want_trace=want_trace, n_iterations=cfg['n_iterations'],
                                 n_alpha_parallel=W, device=device, n_streams=args.streams, riccati=args.riccati,
                                 target_batched=np.ndim(cfg['target']) == 2,
-                                # ranks sharing ONE GPU (--device-wrap, a rehearsal on a one-GPU box): the two-stream overlap
-                                # of accept and recursion is switched off -- with a second process on the same GPU a solve
-                                # stalled for good in 2 of 41 rehearsals, in none of 42 without it
-                                overlap=args.overlap if getattr(args, 'overlap', None) is not None
-                                else (1 if getattr(args, 'device_wrap', False) else 0))
+                                overlap=args.overlap if getattr(args, 'overlap', None) is not None else 0)
         ws.set_weights(cfg['Qk'], cfg['Rk'], cfg['QT'])
         ws.upload(_lib.F_INIT, cfg['init'])
         ws.upload(_lib.F_TARGET, cfg['target'])
@@ -492,7 +488,7 @@ def main():
     ap.add_argument('--no-extra', action='store_true', help='skip the extra_configs block (the other BASELINE configurations)')
     ap.add_argument('--streams', type=int, default=0, help='independent sub-batches of solve(), one HIP stream each (0 = library default)')
     ap.add_argument('--overlap', type=int, default=None, choices=(0, 1, 2), help='accept / recursion overlap: 0 auto, 1 off, 2 on '
-                    '(default: auto, off with --device-wrap)')
+                    '(default: auto)')
     ap.add_argument('--riccati', type=int, default=0, help='backward recursion mapping: 0 auto, 1 lane per problem, 2 lane group')
     ap.add_argument('--force-dist', action='store_true', help='take the torch.distributed (RCCL) path even with one rank')
     ap.add_argument('--backend', default='nccl', choices=('nccl', 'gloo'), help='torch.distributed backend: nccl (= RCCL over xGMI, the '
@@ -509,10 +505,35 @@ def main():
             sys.exit('bench.py: rank(s) failed: %s' % ', '.join('rank %d exit %s' % rc for rc in bad))
         return
 
-    if os.environ.get('ILQR_BENCH_WATCHDOG'):            # development aid: dump every thread's stack if the run stalls
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ['ILQR_BENCH_WATCHDOG']), exit=True)
     rank = int(os.environ.get('RANK', '0'))
+    watched = {}
+    if os.environ.get('ILQR_BENCH_WATCHDOG'):
+        # development aid: if the run has not finished after that many seconds, write every thread's stack and the state of
+        # the workspace's stream (ilqr_ws_query: work pending or not -- a solve has no other queue or event to wait on) to a file
+        # that is kept (gpurun_out/watchdog_rank<r>_pid<p>.txt), and exit non-zero
+        import faulthandler
+        import threading
+
+        def expire():
+            path = os.path.join(ROOT, 'gpurun_out', 'watchdog_rank%d_pid%d.txt' % (rank, os.getpid()))
+            try:
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                with open(path, 'w') as fh:
+                    fh.write('bench.py watchdog: rank %d still running after %s s\n' % (rank, os.environ['ILQR_BENCH_WATCHDOG']))
+                    ws_ = watched.get('ws')
+                    try:
+                        fh.write('workspace stream: %s\n' % ({0: 'idle (nothing pending)', 1: 'work pending'}[ws_.query()] if ws_ else 'no workspace yet'))
+                    except Exception as e:
+                        fh.write('workspace stream query failed: %r\n' % (e,))
+                    fh.flush()
+                    faulthandler.dump_traceback(file=fh, all_threads=True)
+                sys.stderr.write(open(path).read())
+            finally:
+                os._exit(3)
+
+        timer = threading.Timer(float(os.environ['ILQR_BENCH_WATCHDOG']), expire)
+        timer.daemon = True
+        timer.start()
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     args.gpus = world
@@ -553,6 +574,7 @@ def main():
         cfg['n_iterations'] = args.iterations
     N = cfg['N']
     ws = make_workspace(cfg, B, local_rank, args)
+    watched['ws'] = ws
 
     def barrier():
         if dist is not None:

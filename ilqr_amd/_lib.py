@@ -82,6 +82,7 @@ SIGNATURES = {
     'ilqr_ws_mpc_shift': (C.c_int, [_WS, C.c_int32]),
     'ilqr_ws_mpc_solve': (C.c_int, [_WS, C.c_int32]),
     'ilqr_ws_sync': (C.c_int, [_WS]),
+    'ilqr_ws_query': (C.c_int, [_WS]),
     'ilqr_ws_profile': (C.c_int, [_WS, C.c_int32]),
     'ilqr_ws_profile_read': (C.c_int, [_WS, _dp, C.POINTER(C.c_int64)]),
     'ilqr_ws_info': (C.c_int, [_WS, _ip, _ip, C.POINTER(C.c_int64)]),
@@ -266,6 +267,7 @@ class Workspace:
     def mpc_shift(self, span): check(lib().ilqr_ws_mpc_shift(self._h, int(span)))
     def mpc_solve(self, first_call): check(lib().ilqr_ws_mpc_solve(self._h, 1 if first_call else 0))
     def sync(self): check(lib().ilqr_ws_sync(self._h))
+    def query(self): return check(lib().ilqr_ws_query(self._h))     # 0 idle, 1 work pending (non-blocking)
 
     def profile(self, enable=True):
         check(lib().ilqr_ws_profile(self._h, 1 if enable else 0))

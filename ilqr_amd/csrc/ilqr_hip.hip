@@ -249,23 +249,35 @@ int check_launch(const char* what)
 // 512-byte tile row, so the rows it streams are fetched once per CU (W = 64: 8 waves, else 4 waves x 64/W problems;
 // W < 32 covers more).  Workgroups are dealt round-robin over the 8 XCDs, so logical neighbours (which share 128-byte
 // L2 lines) are mapped to block ids 8 apart = the same XCD's L2.  Placement is a speed matter only.
+// Returns false when no kernel is compiled for this (system, width, mode): the caller turns that into an error instead of
+// searching on with stale costs.
 template <class S, int W>
-void launch_ls(hipStream_t st, const KArgs& a, bool ckpt, bool track = false)
+bool launch_ls(hipStream_t st, const KArgs& a, bool ckpt, bool track)
 {
     const long long waves = a.n_tiles * W;          // tiles * 64 problems * W lanes / 64
     constexpr int wpb = W == 64 ? 8 : 4;
     const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
     if constexpr (!lane_recursion_ok<S>) {
         // m > 4: the split schedule only, and widths the staged rollout's LDS records fit (ilqr_ws_create sees to both)
-        if constexpr (W >= 16) hipLaunchKernelGGL((k_linesearch<S, W, true>), dim3(grid), dim3(64 * wpb), 0, st, a);
-        return;
+        if constexpr (W >= 16) {
+            if (track || !ckpt) return false;
+            hipLaunchKernelGGL((k_linesearch<S, W, true>), dim3(grid), dim3(64 * wpb), 0, st, a);
+            return true;
+        }
+        return false;
     }
     else if (track) {
-        // tracking cost: fused schedule only, line-search widths 8 / 16 / 32 (ilqr_ws_create maps the others onto these)
-        if constexpr (W == 8 || W == 16 || W == 32) hipLaunchKernelGGL((k_linesearch<S, W, false, true>), dim3(grid), dim3(64 * wpb), 0, st, a);
+        // tracking cost: fused schedule only, line-search widths 8 / 16 / 32 (ilqr_ws_create maps the automatic choice onto these)
+        if constexpr (W == 8 || W == 16 || W == 32) {
+            if (ckpt) return false;
+            hipLaunchKernelGGL((k_linesearch<S, W, false, true>), dim3(grid), dim3(64 * wpb), 0, st, a);
+            return true;
+        }
+        return false;
     }
     else if (ckpt) hipLaunchKernelGGL((k_linesearch<S, W, true>), dim3(grid), dim3(64 * wpb), 0, st, a);
     else hipLaunchKernelGGL((k_linesearch<S, W, false>), dim3(grid), dim3(64 * wpb), 0, st, a);
+    return true;
 }
 
 int set_device(const ilqr_ws* ws)
@@ -647,7 +659,7 @@ int ws_linesearch(ilqr_ws* ws, int sub = -1)
     const int rounds = ws->ls_rounds_n;
     ProfScope ps(ws, KID_LINESEARCH, st);
     if (rounds > 1) HIPCHK(hipMemsetAsync(cnt, 0, MAX_TRIALS * sizeof(int), st));
-    int j0 = 0;
+    int j0 = 0, unsupported = 0;
     for (int r = 0; r < rounds; ++r) {
         const int Wr = ws->ls_width[r];
         rc = run_pass(ws, KID_LINESEARCH, 0, "k_linesearch", [&](auto S, const KArgs& a0, hipStream_t s) {
@@ -658,18 +670,24 @@ int ws_linesearch(ilqr_ws* ws, int sub = -1)
             a.ls_last = r + 1 == rounds;
             a.ls_count = cnt;
             const bool ck = ws->split != 0, tr = ws->d.tracking != 0;
+            bool launched = false;
             switch (Wr) {
-                case 1: launch_ls<T, 1>(s, a, ck); break;
-                case 2: launch_ls<T, 2>(s, a, ck); break;
-                case 4: launch_ls<T, 4>(s, a, ck); break;
-                case 8: launch_ls<T, 8>(s, a, ck, tr); break;
-                case 16: launch_ls<T, 16>(s, a, ck, tr); break;
-                case 32: launch_ls<T, 32>(s, a, ck, tr); break;
-                default: launch_ls<T, 64>(s, a, ck); break;
+                case 1: launched = launch_ls<T, 1>(s, a, ck, tr); break;
+                case 2: launched = launch_ls<T, 2>(s, a, ck, tr); break;
+                case 4: launched = launch_ls<T, 4>(s, a, ck, tr); break;
+                case 8: launched = launch_ls<T, 8>(s, a, ck, tr); break;
+                case 16: launched = launch_ls<T, 16>(s, a, ck, tr); break;
+                case 32: launched = launch_ls<T, 32>(s, a, ck, tr); break;
+                case 64: launched = launch_ls<T, 64>(s, a, ck, tr); break;
+                default: break;
             }
+            if (!launched) { unsupported = Wr; return; }
             if (!a.ls_last) hipLaunchKernelGGL(k_ls_compact, dim3((unsigned)((a.n_tiles * TILE + 1023) / 1024)), dim3(1024), 0, s, a);
         }, sub, false);
         if (rc) return rc;
+        if (unsupported)
+            return fail(-1, "line search: no kernel is compiled for %d trials per round with this system%s (tracking cost: 8, 16, 32; "
+                        "more than 4 inputs: 16, 32, 64 on the split schedule)", unsupported, ws->d.tracking ? " and the tracking cost" : "");
         j0 += Wr;
     }
     return 0;
@@ -750,7 +768,7 @@ int run_sharded(const ilqr_desc* d, F&& fn)
     if (!d->device_wrap && (d->device < 0 || d->device + G > ndev))
         return fail(-1, "devices %d..%d requested, %d visible (device_wrap = 1 lets shards share a device)", d->device, d->device + G - 1, ndev);
     const long long B = d->batch, base = B / G, rem = B % G;
-    std::vector<int> rcs(G, 0);
+    std::vector<int> rcs(G, 0), devs(G, -1);
     std::vector<std::string> errs(G);
     std::vector<std::thread> threads;
     threads.reserve(G);
@@ -762,9 +780,18 @@ int run_sharded(const ilqr_desc* d, F&& fn)
         sd.batch = cnt;
         sd.device = d->device_wrap ? (((d->device + r) % ndev) + ndev) % ndev : d->device + r;
         try {
+            devs[r] = sd.device;
             threads.emplace_back([&, r, lo, sd] {
-                rcs[r] = fn(sd, lo);
-                if (rcs[r]) errs[r] = g_err;             // g_err is per thread: hand the message to the caller's
+                try {
+                    rcs[r] = fn(sd, lo);
+                    if (rcs[r]) errs[r] = g_err;         // g_err is per thread: hand the message to the caller's
+                } catch (const std::exception& e) {      // (std::bad_alloc of a host vector, ...): an error code, never std::terminate
+                    rcs[r] = -4;
+                    errs[r] = std::string("exception in the shard's host thread: ") + e.what();
+                } catch (...) {
+                    rcs[r] = -4;
+                    errs[r] = "unknown exception in the shard's host thread";
+                }
             });
         } catch (const std::exception& e) {              // no thread to be had: nothing may leave this function as a C++ exception
             rcs[r] = -1;
@@ -774,7 +801,7 @@ int run_sharded(const ilqr_desc* d, F&& fn)
     }
     for (auto& t : threads) t.join();
     for (int r = 0; r < G; ++r)
-        if (rcs[r]) return fail(rcs[r], "shard %d of %d (device %d): %s", r, G, d->device + r, errs[r].c_str());
+        if (rcs[r]) return fail(rcs[r], "shard %d of %d (device %d): %s", r, G, devs[r], errs[r].c_str());
     return 0;
 }
 // p + count elements, keeping an optional (null) argument null
@@ -1284,6 +1311,17 @@ int ilqr_ws_sync(ilqr_ws* ws)
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ws->stream));
     return 0;
+}
+
+int ilqr_ws_query(ilqr_ws* ws)
+{
+    if (!ws) return fail(-1, "null workspace");
+    int rc = set_device(ws);
+    if (rc) return rc;
+    const hipError_t e = hipStreamQuery(ws->stream);
+    if (e == hipSuccess) return 0;
+    if (e == hipErrorNotReady) return 1;
+    return fail(-100 - (int)e, "hipStreamQuery: %s", hipGetErrorString(e));
 }
 
 int ilqr_ws_profile(ilqr_ws* ws, int32_t enable)

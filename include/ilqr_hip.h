@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ILQR_ABI_VERSION 7
+#define ILQR_ABI_VERSION 8
 
 /* systems compiled into the library (sympy-generated __device__ dynamics, ilqr_amd/csrc/dynamics/) */
 enum { ILQR_SYS_PENDULUM = 0, ILQR_SYS_ACROBOT = 1, ILQR_SYS_CARTPOLE = 2, ILQR_SYS_QUADCOPTER = 3, ILQR_SYS_CAR = 4,
@@ -160,7 +160,12 @@ int ltvlqr_batched(const ilqr_desc* d, int32_t n_state_rows, const double* state
  *     not fit is refused with ILQR_ERR_SCRATCH (the message names the largest batch for that horizon: about
  *     64 * floor(64 MiB / (64 * 8 * ((N+1) n + N m + N m n + P))) problems, e.g. 256 acrobot problems of 3000 steps).
  *   - Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race.
- *     d->n_devices must be 0 or 1. */
+ *     d->n_devices must be 0 or 1.
+ *   - The FIRST call on a device resolves the array's address there (hipGetSymbolAddress, under a mutex): make one
+ *     warm-up call per device before a stream capture begins.  Later calls issue kernels and hipMemcpyAsync /
+ *     hipMemsetAsync on `stream` only.  Running it UNDER hipStreamBeginCapture has not been exercised by the tests.
+ *   - Padding lanes (B not a multiple of 64) are filled by the pack kernels with copies of problem B - 1 on every call:
+ *     no lane computes on a previous call's data. */
 #define ILQR_NOALLOC_SCRATCH_BYTES (64 * 1024 * 1024)
 #define ILQR_ERR_SCRATCH (-6)
 int ltvlqr_device_noalloc(const ilqr_desc* d, int32_t n_state_rows, const double* states, const double* inputs,
@@ -225,6 +230,11 @@ int ilqr_ws_ltvlqr(ilqr_ws* ws);           /* ltvlqr.py:3-28 on STATES/INPUTS ->
 int ilqr_ws_mpc_shift(ilqr_ws* ws, int32_t span);
 int ilqr_ws_mpc_solve(ilqr_ws* ws, int32_t first_call);
 int ilqr_ws_sync(ilqr_ws* ws);
+/* Non-blocking state of the workspace's stream (a solve uses that ONE stream and no events of its own since ABI 8):
+ * 0 = every pass enqueued so far has completed, 1 = work still pending, < 0 = the stream reports an error (ilqr_last_error).
+ * No counterpart in the reference; a diagnosis aid -- a watchdog can tell "still computing" from "stalled with nothing
+ * running" without blocking in ilqr_ws_sync (bench.py prints it when ILQR_BENCH_WATCHDOG expires). */
+int ilqr_ws_query(ilqr_ws* ws);
 /* kernel timing with HIP events on the workspace stream.  kernel ids: 0 rollout, 1 backward, 2 linesearch, 3 accept,
  * 4 ltvlqr, 5 forward, 6 cost, 7 linearize.  In the split pipeline backward = k_riccati, accept = k_save_boundaries + k_accept_lin (which also writes A_t, B_t); linesearch = all rounds of a pass.
  * ms[i] = summed duration, launches[i] = count since the last enable. */

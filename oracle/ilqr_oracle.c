@@ -388,11 +388,11 @@ int oracle_ltvlqr_batched(int sys, int64_t B, int N, int n_rows, const double* s
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #endif
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) reduction(min : rc)
     for (int64_t b = 0; b < B; ++b) {
         int r = oracle_ltvlqr(sys, N, states + b * (int64_t)n_rows * n, inputs + b * (int64_t)N * m, Qk, Rk, QT, dt,
                               params + b * param_stride, K_out + b * (int64_t)N * m * n);
-        if (r != 0) rc = r;
+        if (r < rc) rc = r;                         /* error codes are negative */
     }
     return rc;
 }

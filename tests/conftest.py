@@ -53,3 +53,23 @@ def oracle():
     from oracle import oracle as O
     O.lib()
     return O
+
+
+def sample_batch(name):
+    """The first problems of one of bench.py's random batches (BASELINE configs[1], [3], [4]) together with what the REFERENCE
+    class returned for them (tests/golden/<name>_sample.npz, written by tools/make_golden.py samples): inputs, fixture."""
+    import bench
+    g = golden(name + '_sample')
+    cnt = int(g['count'])
+    w = bench.workload(name, bench.DEFAULT_BATCH[name], 0)
+    N = w['N']
+    assert np.array_equal(w['init'][:cnt], g['init'])                       # the fixture belongs to this workload
+    chk = np.array([float(np.sum(w['guess'][b] * np.arange(1, N + 1)[:, None])) for b in range(cnt)])
+    assert np.array_equal(chk, g['guess_checksum'])
+    return w, g, cnt
+
+
+def problem_dist(a, b):
+    """per problem (leading axis), norm-wise as rel_err"""
+    ax = tuple(range(1, np.ndim(a)))
+    return np.max(np.abs(a - b), axis=ax) / np.max(np.abs(b), axis=ax) if ax else np.abs(a - b) / np.abs(b)

@@ -177,7 +177,7 @@ def test_library_exports_every_declared_symbol():
     for nme in names:
         assert hasattr(handle, nme), nme
     assert sorted(_lib.SIGNATURES) == names      # the python binding covers the header exactly
-    assert _lib.lib().ilqr_abi_version() == 7
+    assert _lib.lib().ilqr_abi_version() == 8
 
 
 def test_library_host_side_calls_without_gpu():
@@ -286,6 +286,34 @@ def test_headline_batch_rounding_noise_floor(oracle):
     assert np.array_equal(a['trace'][0, :, 4], g['trace'][:, 4])
     assert rel_err(a['states'][0], g['states']) < TOL and rel_err(a['K'][0], g['K']) < TOL and rel_err(a['inputs'][0], g['inputs']) < TOL
     assert abs(a['cost'][0] - float(g['cost'])) <= TOL * abs(float(g['cost']))
+
+
+@pytest.mark.parametrize('name', ['c2', 'c4', 'c5'])
+def test_random_bench_batches_against_the_reference_itself(oracle, name):
+    """The noise-floor argument of the test above, backed by numpy instead of by the oracle's sibling build: the first 32 / 16 / 8
+    problems of bench.py's random C2 / C4 / C5 batches were solved by the REFERENCE class (ilqr.py:159-211, 10 iterations;
+    tools/make_golden.py samples).  The oracle must take the reference's decision in every line search of every problem, end
+    with its status and iteration count -- and sit no further from the reference than it sits from itself rebuilt with fused
+    multiply-adds (quantile by quantile, 8x slack for samples this small): the spread is the problems' sensitivity to last-bit
+    rounding, measured against numpy."""
+    from conftest import problem_dist, sample_batch
+    w, g, cnt = sample_batch(name)
+    tgt = w['target'][:cnt] if np.ndim(w['target']) == 2 else w['target']
+    args = (w['system'], w['init'][:cnt], tgt, w['guess'][:cnt], w['Qk'], w['Rk'], w['QT'], w['dt'], w['params'], int(g['n_iterations']))
+    o, f = oracle.solve_batched(*args), oracle.solve_batched(*args, fma=True)
+    assert np.array_equal(o['trace'][:, :, 4], g['trace'][:, :, 4], equal_nan=True)          # accepted trial of every search
+    assert np.array_equal(o['status'], g['status']) and np.array_equal(o['iters'], g['iters'])
+    ts, tx = g['rows_inputs'], g['rows_states']
+    report = {}
+    for key, ora, ref, fma in (('cost', o['cost'], g['cost'], f['cost']), ('states', o['states'][:, tx], g['states'], f['states'][:, tx]),
+                               ('inputs', o['inputs'][:, ts], g['inputs'], f['inputs'][:, ts]), ('K', o['K'][:, ts], g['K'], f['K'][:, ts])):
+        q_ref, q_flr = (np.quantile(problem_dist(a, b), [0.5, 0.9, 1.0]) for a, b in ((ora, ref), (fma, ora)))
+        report[key] = (q_ref, q_flr)
+        assert np.all(q_ref <= 8.0 * q_flr + 1e-13), (name, key, q_ref, q_flr)
+    if name == 'c5':        # the quadcopter batch is the well-conditioned one: the 1e-8 bar itself holds on cost and states
+        assert report['cost'][0][2] < 1e-10 and report['states'][0][2] < TOL
+    print(name, 'oracle-vs-reference | oracle-vs-oracle(FMA) quantiles [50, 90, 100]:',
+          {k_: [list(np.round(v, 13)) for v in vv] for k_, vv in report.items()})
 
 
 def test_mpc_restatement_reduces_to_ilqr_py(oracle):

@@ -267,6 +267,45 @@ def test_c5_quadcopter_32768(amd, oracle):
     compare_sample_with_oracle(oracle, 'quadcopter', g, init, guess, target, ws, [0, 9, 32767], 10)
 
 
+@pytest.mark.parametrize('name', ['c2', 'c4', 'c5'])
+def test_random_bench_batches_against_the_reference_itself(amd, oracle, name):
+    """bench.py's own random batches at full size (C2 4096, C4 131 072, C5 32 768 problems, 10 iterations): their first 32 / 16 / 8
+    problems were solved by the REFERENCE class (tools/make_golden.py samples -> tests/golden/<name>_sample.npz).  The GPU,
+    solving them inside the full batch, must take the reference's decision in every line search (cartpole: through
+    iteration 5 for every problem, at most one problem flipping later -- see test_c4_cartpole_131072), and sit no
+    further from the reference than the CPU oracle sits from itself rebuilt with fused multiply-adds (8x slack, samples
+    this small): numpy, not the oracle, is the yardstick here."""
+    import bench
+    from conftest import problem_dist, sample_batch
+    from ilqr_amd import _lib
+    w, g, cnt = sample_batch(name)
+    batched_target = np.ndim(w['target']) == 2
+    ws = solve_ws(amd, w['system'], w, w['init'], w['guess'], w['target'], int(g['n_iterations']), target_batched=batched_target)
+    trace, status, iters, cost = (ws.download(f)[:cnt] for f in (_lib.F_TRACE, _lib.F_STATUS, _lib.F_ITERS, _lib.F_COST))
+    ts, tx = g['rows_inputs'], g['rows_states']
+    states, inputs, K = ws.download(_lib.F_STATES)[:cnt][:, tx], ws.download(_lib.F_INPUTS)[:cnt][:, ts], ws.download(_lib.F_KFB)[:cnt][:, ts]
+    ws.close()
+    same = (trace[:, :, 4] == g['trace'][:, :, 4]) | (np.isnan(trace[:, :, 4]) & np.isnan(g['trace'][:, :, 4]))
+    if name == 'c4':
+        assert same[:, :6].all() and (~same.all(1)).sum() <= 1, np.argwhere(~same)[:5]
+    else:
+        assert same.all(), np.argwhere(~same)[:5]
+        assert np.array_equal(status, g['status']) and np.array_equal(iters, g['iters'])
+    keep = same.all(1)                                   # a flipped decision is another sequence of steps: not a rounding distance
+    tgt = w['target'][:cnt] if batched_target else w['target']
+    args = (w['system'], w['init'][:cnt], tgt, w['guess'][:cnt], w['Qk'], w['Rk'], w['QT'], w['dt'], w['params'], int(g['n_iterations']))
+    o, f = oracle.solve_batched(*args), oracle.solve_batched(*args, fma=True)
+    report = {}
+    for key, gpu, ref, a, b in (('cost', cost, g['cost'], f['cost'], o['cost']), ('states', states, g['states'], f['states'][:, tx], o['states'][:, tx]),
+                                ('inputs', inputs, g['inputs'], f['inputs'][:, ts], o['inputs'][:, ts]), ('K', K, g['K'], f['K'][:, ts], o['K'][:, ts])):
+        q_gpu, q_flr = np.quantile(problem_dist(gpu[keep], ref[keep]), [0.5, 0.9, 1.0]), np.quantile(problem_dist(a, b), [0.5, 0.9, 1.0])
+        report[key] = (q_gpu, q_flr)
+        assert np.all(q_gpu <= 8.0 * q_flr + 1e-13), (name, key, q_gpu, q_flr)
+    if name == 'c5':
+        assert report['cost'][0][2] < 1e-10 and report['states'][0][2] < TOL
+    print(name, 'GPU-vs-reference | oracle-vs-oracle(FMA) quantiles [50, 90, 100]:', {k_: [list(np.round(v, 13)) for v in vv] for k_, vv in report.items()})
+
+
 @pytest.mark.parametrize('system,B,N', [('pendulum', 65536, 300), ('acrobot', 32768, 200)])
 def test_widening_round_schedule_changes_nothing(amd, system, B, N):
     """auto width on a batch that fills the chip several times over runs rounds of 4, 4, 8, 16, 16, 16 trials instead of
