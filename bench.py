@@ -247,7 +247,7 @@ def make_workspace(cfg, B, device, args, want_trace=True):
     else:
         W = args.alphas if args.alphas else cfg['W']
         ws = ilqr_amd.Workspace(cfg['system'], cfg['N'], B, cfg['dt'], want_trace=want_trace, n_iterations=cfg['n_iterations'],
-                                n_alpha_parallel=W, device=device, n_streams=args.streams, riccati=args.riccati,
+                                n_alpha_parallel=W, device=device, n_streams=args.streams, riccati=args.riccati, pipeline=getattr(args, 'pipeline', 0),
                                 target_batched=np.ndim(cfg['target']) == 2,
                                 overlap=args.overlap if getattr(args, 'overlap', None) is not None else 0)
         ws.set_weights(cfg['Qk'], cfg['Rk'], cfg['QT'])
@@ -490,6 +490,7 @@ def main():
     ap.add_argument('--overlap', type=int, default=None, choices=(0, 1, 2), help='accept / recursion overlap: 0 auto, 1 off, 2 on '
                     '(default: auto)')
     ap.add_argument('--riccati', type=int, default=0, help='backward recursion mapping: 0 auto, 1 lane per problem, 2 lane group')
+    ap.add_argument('--pipeline', type=int, default=0, help='kernel schedule: 0 auto, 1 fused, 2 split (same results)')
     ap.add_argument('--force-dist', action='store_true', help='take the torch.distributed (RCCL) path even with one rank')
     ap.add_argument('--backend', default='nccl', choices=('nccl', 'gloo'), help='torch.distributed backend: nccl (= RCCL over xGMI, the '
                     'real thing) or gloo (rehearsal of the N > 1 path where the ranks cannot each have a GPU)')

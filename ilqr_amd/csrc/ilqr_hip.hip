@@ -991,7 +991,9 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
     // pipeline: with few tiles the horizon-sequential kernels occupy one wave per tile and leave most of the 1024 SIMDs
     // idle, so the parallel parts (accept re-roll, Jacobians) are split off; large batches fill the chip either way and
     // keep the fused kernels (no LIN / checkpoint traffic).
-    ws->split = d->pipeline == 2 || (d->pipeline == 0 && ws->tiles < 1024);
+    // Crossover measured in round 3 (profiles/r3_pipeline_crossover.txt): acrobot 16 384 problems split 125 k vs fused 117 k
+    // solves/s, 32 768 problems split 131 k vs fused 148 k; cartpole and pendulum the same picture (32 768: fused +16 % / +10 %)
+    ws->split = d->pipeline == 2 || (d->pipeline == 0 && ws->tiles < 512);
     if (d->n_iterations == 0 || d->tracking) ws->split = 0;
     // Riccati recursion: one lane per problem while V_xx fits its registers (n <= 4), a lane group with LDS hand-offs
     // beyond (always through the split schedule, which provides LIN); riccati = 1 / 2 forces lane / group

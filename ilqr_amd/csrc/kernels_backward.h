@@ -86,25 +86,16 @@ __global__ void __launch_bounds__(64) k_backward(const KArgs a)
             for (int i = 0; i < n; ++i) ex[i] = x[i] - xd[i];
 #pragma unroll
             for (int j = 0; j < m; ++j) du[j] = u[j] - ud[j];
-            if constexpr (n > 4) {
-                // rolled, Q_k read from memory: with Q_k's 144 entries unrolled into this kernel's registers next to
-                // V_xx, A and Q_xx, hipcc 7.2 -O3 emits a kernel that computes wrong gains (correct at -O1 and without
-                // this product; tools/dbg notes in DESIGN.md).  ex and lx are indexed dynamically, i.e. live in scratch.
-#pragma nounroll
-                for (int i = 0; i < n; ++i) {
-                    double s = 0.0;
-#pragma nounroll
-                    for (int c = 0; c < n; ++c) s = __builtin_fma(a.WTS[i * n + c], ex[c], s);
-                    lx[i] = s;
-                }
-            } else {
+            // ilqr_mpc.m:260  l_x = Q_k (x - x_des).  (Round 2 rolled this product for n > 4 after "wrong gains at -O3": round 3
+            // found the recursion itself unstable for the Q_k that was used -- the CPU restatement against itself, states 1e-13
+            // apart, ends O(1) apart after the quadcopter's 400 steps once Q_k ~ 0.1 -- and both forms equal to the restatement
+            // wherever it is conditioned: tests/test_gpu_mpc.py::test_tracking_backward_pass_and_cost_with_a_dense_Qk.)
 #pragma unroll
-                for (int i = 0; i < n; ++i) {                                          // ilqr_mpc.m:260  l_x = Q_k (x - x_des)
-                    double s = 0.0;
+            for (int i = 0; i < n; ++i) {
+                double s = 0.0;
 #pragma unroll
-                    for (int c = 0; c < n; ++c) s = __builtin_fma(Qk[i * n + c], ex[c], s);
-                    lx[i] = s;
-                }
+                for (int c = 0; c < n; ++c) s = __builtin_fma(Qk[i * n + c], ex[c], s);
+                lx[i] = s;
             }
             ok = Riccati<S>::template step<true>(A, Bm, du, Qk, Rk, a.quu_reg, Vx, Vxx, k, K, g, h, lx) && ok;
         } else {

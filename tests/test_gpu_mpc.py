@@ -159,3 +159,54 @@ def test_tracking_kernels_reduce_to_the_pinned_path_bitwise(amd, system):
     a.cost(); b.cost(); a.sync(); b.sync()
     assert np.array_equal(a.download(_lib.F_COST), b.download(_lib.F_COST))
     a.close(); b.close()
+
+
+@pytest.mark.parametrize('system', ['quadcopter', 'acrobot', 'car'])
+def test_tracking_backward_pass_and_cost_with_a_dense_Qk(amd, oracle, system):
+    """One teacher-forced pass of the tracking kernels with a DENSE, non-zero Q_k and targets away from the trajectory, per
+    kernel against the restatement: k_backward<TRACK> (gains k, K and the three expected reductions; l_x = Q_k (x - x_des),
+    ilqr_mpc.m:260) and k_cost<TRACK> (stage cost with the full quadratic form in x, :207-209) -- every entry of Q_k in play.
+    Conditioning decides what can be asked.  The reference's recursion (explicit inverse, V_xx never symmetrised) is UNSTABLE
+    for the quadcopter once Q_k reaches ~0.1: a 1e-13 perturbation of the states grows ~100x per 50 steps and is O(1) after
+    the example's 400 (measured on the CPU restatement against itself, see below) -- which is what round 2 took for a
+    compiler bug in k_backward<quadcopter, TRACK> ("wrong gains at -O3, right at -O1": two roundings of one unstable
+    recursion).  So: the large Q_k over a horizon short enough to stay conditioned (120 steps), a Q_k of the example's size
+    (1e-3, example_acrobot_ilqr_mpc.m:13) over the whole horizon, and the instability itself asserted on the checker."""
+    from ilqr_amd import _lib
+    p = golden(system + '_passes')
+    N, n, m = p['inputs0'].shape[0], p['states0'].shape[1], p['inputs0'].shape[1]
+    rng = np.random.default_rng(11)
+    M = rng.standard_normal((n, n))
+    big = 0.01 * (M @ M.T) + 0.002 * np.eye(n)                      # dense, symmetric positive definite, entries up to ~0.15
+    Bn = 3
+    xs = np.stack([p['states0'] + 0.01 * b * rng.standard_normal(p['states0'].shape) for b in range(Bn)])
+    us = np.stack([p['inputs0'] + 0.01 * b * rng.standard_normal(p['inputs0'].shape) for b in range(Bn)])
+    xd = xs + 0.05 * rng.standard_normal(xs.shape)
+    ud = us + 0.05 * rng.standard_normal(us.shape)
+    for Qk, Nuse in ((big, min(N, 120)), (0.01 * big, N)):
+        ws = amd.Workspace(system, Nuse, Bn, float(p['dt']), want_trace=False, n_iterations=1, tracking=True, zero_first_state=False,
+                           pipeline=1, low_expected_reduction=0.0)
+        ws.set_weights(Qk, p['Rk'], p['QT'])
+        ws.upload(_lib.F_PARAMS, p['params'])
+        sl = (xs[:, :Nuse + 1], us[:, :Nuse], xd[:, :Nuse + 1], ud[:, :Nuse])
+        for f, a in zip((_lib.F_STATES, _lib.F_INPUTS, _lib.F_TARGET_STATES, _lib.F_TARGET_INPUTS), sl):
+            ws.upload(f, np.ascontiguousarray(a))
+        ws.cost()
+        cost = ws.download(_lib.F_COST)
+        ws.backward(0)
+        k, K, dJ = ws.download(_lib.F_KFF), ws.download(_lib.F_KFB), ws.download(_lib.F_DJ)
+        ws.close()
+        for b in range(Bn):
+            c_ref = oracle.mpc_cost(sl[0][b], sl[1][b], sl[2][b], sl[3][b], Qk, p['Rk'], p['QT'])
+            assert abs(cost[b] - c_ref) <= 1e-12 * abs(c_ref), (b, cost[b], c_ref)
+            k_ref, K_ref, dJ_ref = oracle.mpc_backward(system, sl[0][b], sl[1][b], sl[2][b], sl[3][b], Qk, p['Rk'], p['QT'], float(p['dt']), p['params'])
+            tol = 1e-7 if system == 'quadcopter' else 1e-8   # (the restatement SOLVES with Q_uu, the kernels multiply by its inverse: 3e-9 on the quadcopter's K)
+            errs = (rel_err(K[b], K_ref), rel_err(k[b], k_ref), rel_err(dJ[b], dJ_ref))
+            assert max(errs) < tol, (system, Nuse, b, errs)
+    if system == 'quadcopter':
+        # the instability, on the checker alone: the same pass twice, the states 1e-13 apart
+        args = (big, p['Rk'], p['QT'], float(p['dt']), p['params'])
+        _, K1, _ = oracle.mpc_backward(system, xs[0], us[0], xd[0], ud[0], *args)
+        _, K2, _ = oracle.mpc_backward(system, xs[0] + 1e-13 * rng.standard_normal(xs[0].shape), us[0], xd[0], ud[0], *args)
+        growth = np.max(np.abs(K2 - K1), axis=(1, 2)) / np.max(np.abs(K1))
+        assert growth[-1] < 1e-12 and growth[0] > 1e-3, (growth[-1], growth[0])       # last step: rounding; first step: O(1)

@@ -18,7 +18,7 @@ from ilqr_amd import _lib
 
 name = sys.argv[1] if len(sys.argv) > 1 else 'c2'
 B = int(sys.argv[2]) if len(sys.argv) > 2 else bench.DEFAULT_BATCH[name]
-args = argparse.Namespace(alphas=0, streams=0, riccati=0, overlap=None, device_wrap=False)
+args = argparse.Namespace(alphas=0, streams=0, riccati=0, overlap=None, device_wrap=False, pipeline=0)
 cfg = bench.workload(name, B, 0)
 ws = bench.make_workspace(cfg, B, 0, args)
 one = {'ltvlqr': ws.ltvlqr, 'mpc': lambda: (ws.mpc_shift(1), ws.mpc_solve(False))}.get(cfg['kind'], ws.solve)
