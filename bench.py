@@ -347,9 +347,13 @@ def add_pmc(roofline, dominant, pmc, extra, work, cfg):
     kernel's VALU instructions per trial step, PMC, against 2 flops per lane and slot)."""
     if pmc is None:
         return
-    k = pmc['kernels'].get('k_' + dominant)
-    if not k:
+    # bench.py times passes (HIP events around a pass); the kernel behind a pass depends on the schedule
+    names = {'backward': ('k_backward', 'k_riccati_grp', 'k_riccati', 'k_accept_riccati', 'k_riccati_quad'), 'accept': ('k_forward', 'k_accept_lin')}
+    name = next((c for c in names.get(dominant, ('k_' + dominant,)) if c in pmc['kernels']), None)
+    if name is None:
         return
+    k = pmc['kernels'][name]
+    roofline['kernel_profiled'] = name
     roofline['traffic'] = round(k['hbm_bytes_per_launch'] / 1e9, 3)
     roofline['traffic_unit'] = ('GB per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic_%s.json, kernel sources %s)'
                                 % (pmc['config'].get('name', 'c2'), pmc['source_hash']))

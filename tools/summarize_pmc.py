@@ -18,7 +18,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import source_hash       # hash of the kernel sources the counters were taken on (bench.py drops stale traffic)
 
-KERNELS = ('k_linesearch', 'k_ls_compact', 'k_riccati_grp', 'k_riccati_quad', 'k_riccati', 'k_accept_lin', 'k_save_boundaries',
+KERNELS = ('k_linesearch', 'k_ls_compact', 'k_accept_riccati', 'k_riccati_grp', 'k_riccati_quad', 'k_riccati', 'k_accept_lin', 'k_save_boundaries',
            'k_linearize', 'k_rollout', 'k_cost', 'k_backward', 'k_forward', 'k_ltvlqr', 'k_mpc_shift')
 
 
