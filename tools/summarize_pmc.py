@@ -37,7 +37,12 @@ def ls_width(name):
 def main():
     d = sys.argv[1]
     out = collections.defaultdict(dict)
-    for f in sorted(glob.glob(os.path.join(d, 'pmc_*', '*', '*_counter_collection.csv'))):
+    files = []
+    for sub in sorted(glob.glob(os.path.join(d, 'pmc_*'))):      # one pass per directory: its NEWEST collection only
+        cand = glob.glob(os.path.join(sub, '*', '*_counter_collection.csv'))
+        if cand:
+            files.append(max(cand, key=os.path.getmtime))
+    for f in files:
         rows = list(csv.DictReader(open(f)))
         # rounds of one search: line-search launches in dispatch order since the last backward / accept kernel
         disp = {}
