@@ -226,7 +226,10 @@ int ilqr_ws_ltvlqr(ilqr_ws* ws);           /* ltvlqr.py:3-28 on STATES/INPUTS ->
  *   ilqr_ws_mpc_solve(ws, first_call): first call only, one backward pass along the window for the gains (:75-78); then
  *     the closed-loop rollout with learning rate 0 (:127-134) and n_iterations x {backward, line search, accept}
  *     (:142-184) -> STATES, INPUTS, KFF, KFB, COST as solve().  The while condition of the line search is
- *     `learning_rate > low_learning_rate` there (:158): set search_floor = low_learning_rate (the defaults are equal). */
+ *     `learning_rate > low_learning_rate` there (:158): set search_floor = low_learning_rate (the defaults are equal).
+ * zero_first_state = 1 is not refused with tracking = 1: it applies ilqr.py's row-0 quirk to the tracking kernels, which is
+ * what lets tests/test_gpu_mpc.py reduce them to the pinned ilqr.py path bit for bit; ilqr_mpc.m itself never zeroes row 0
+ * and the python class ilqr_amd.ilqr_mpc always passes 0. */
 int ilqr_ws_mpc_shift(ilqr_ws* ws, int32_t span);
 int ilqr_ws_mpc_solve(ilqr_ws* ws, int32_t first_call);
 int ilqr_ws_sync(ilqr_ws* ws);
