@@ -83,9 +83,11 @@ def _tiled(block, B):
 
 def workload(name, B, seed):
     """The synthetic inputs of one BASELINE configuration, B problems (one GPU's share)."""
-    if name == 'c2':
+    if name in ('c2', 'c2_no_stop'):
         cfg = acrobot_c2(B, seed)
         cfg.update(kind='solve', n_iterations=10, W=0, label='acrobot swing-up iLQR (BASELINE configs[1]): n=4 m=1 N=3000')
+        if name == 'c2_no_stop':
+            cfg.update(no_stop=True, label=cfg['label'] + ', stop tests disabled (every problem runs every pass: the pure per-pass time)')
         return cfg
     if name == 'c3':                                       # ltvlqr along perturbed copies of the reference's own CSV trajectory
         csv, g = golden('acrobot_csv'), golden('acrobot_ltvlqr')
@@ -149,7 +151,7 @@ def workload(name, B, seed):
     raise ValueError('unknown config %r' % name)
 
 
-DEFAULT_BATCH = {'c2': 4096, 'c3': 65536, 'c4': 131072, 'c4_w8': 131072, 'c5': 32768, 'pendulum': 131072, 'acrobot_big': 65536,
+DEFAULT_BATCH = {'c2': 4096, 'c2_no_stop': 4096, 'c3': 65536, 'c4': 131072, 'c4_w8': 131072, 'c5': 32768, 'pendulum': 131072, 'acrobot_big': 65536,
                  'mpc': 65536, 'floating_base': 16384}
 
 
@@ -246,10 +248,13 @@ def make_workspace(cfg, B, device, args, want_trace=True):
         ws.upload(_lib.F_INPUTS, cfg['inputs'])
     else:
         W = args.alphas if args.alphas else cfg['W']
+        # no_stop (the second figure): the "optimal" test never fires (threshold 0) and an exhausted search does not
+        # end the solve (ilqr.py:204 with a threshold below every trial's rate): every problem runs every pass
+        stops = dict(low_expected_reduction=0.0, low_learning_rate=1e-300) if cfg.get('no_stop') else {}
         ws = ilqr_amd.Workspace(cfg['system'], cfg['N'], B, cfg['dt'], want_trace=want_trace, n_iterations=cfg['n_iterations'],
                                 n_alpha_parallel=W, device=device, n_streams=args.streams, riccati=args.riccati, pipeline=getattr(args, 'pipeline', 0),
                                 target_batched=np.ndim(cfg['target']) == 2,
-                                overlap=args.overlap if getattr(args, 'overlap', None) is not None else 0)
+                                overlap=args.overlap if getattr(args, 'overlap', None) is not None else 0, **stops)
         ws.set_weights(cfg['Qk'], cfg['Rk'], cfg['QT'])
         ws.upload(_lib.F_INIT, cfg['init'])
         ws.upload(_lib.F_TARGET, cfg['target'])
@@ -424,6 +429,9 @@ def extra_config(name, args):
            'kernels_ms_per_pass': {k_: round(v['ms_per_pass'], 3) for k_, v in kern.items()},
            'kernels_hbm_frac': {k_: round(v['gbs'] / HBM_PEAK_GBS, 4) for k_, v in kern.items() if v['gbs'] > 0},
            'kernels_fp64_frac': {k_: round(v['tflops'] / FP64_PEAK_TFLOPS, 4) for k_, v in kern.items() if v['tflops'] > 0}}
+    if cfg.get('no_stop'):
+        once = sum(kern[k_]['ms_per_pass'] for k_ in ('rollout', 'linearize') if k_ in kern)
+        out['ms_per_bwd_fwd_pass'] = round((1e3 * elapsed / steps - once) / cfg['n_iterations'], 4)
     if cfg['kind'] in ('solve', 'mpc'):
         st = extra['status']
         out['exit_status_counts'] = {n_: int((st == s).sum()) for s, n_ in ((0, 'max_iter'), (1, 'optimal'), (2, 'low_learning_rate'), (3, 'numerical'))}
@@ -655,8 +663,8 @@ def main():
         status, trace = extra['status'], extra['trace']
         out['config']['n_iterations'] = cfg['n_iterations']
         # one backward + line search + accept pass, from the wall clock of the step (the accept step of iteration i and the
-        # recursion of iteration i + 1 run overlapped on two streams: their per-kernel times overlap, the sum would count
-        # that time twice): (step - initial rollout - initial linearisation) / iterations
+        # recursion of iteration i + 1 share launches: the per-kernel times are not additive): (step - initial rollout -
+        # initial linearisation) / iterations
         once_ms = sum(kern[k_]['ms_per_pass'] for k_ in ('rollout', 'linearize') if k_ in kern)
         out['ms_per_bwd_fwd_pass'] = round((1e3 * elapsed / args.steps - once_ms) / max(cfg['n_iterations'], 1), 4)
         out['exit_status_counts'] = {_lib.STATUS_NAMES[s]: int((status == s).sum()) for s in range(4)}
@@ -685,7 +693,7 @@ def main():
     ws.close()
     if world == 1 and not args.no_extra and args.config == 'c2' and not strong and args.batch in (0, DEFAULT_BATCH['c2']):
         out['extra_configs'] = {}
-        for name in ('c3', 'c4', 'c4_w8', 'c5', 'pendulum', 'acrobot_big', 'mpc', 'floating_base'):
+        for name in ('c2_no_stop', 'c3', 'c4', 'c4_w8', 'c5', 'pendulum', 'acrobot_big', 'mpc', 'floating_base'):
             try:
                 out['extra_configs'][name] = extra_config(name, args)
             except Exception as e:                             # an extra block must never cost the headline line
