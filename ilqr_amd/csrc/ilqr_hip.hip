@@ -950,18 +950,21 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
     ws->W = W;
     // Round widths.  Fixed (every round W trials) when the caller chose W or the batch is small enough that a round is a
     // latency-bound pass over the horizon (fewer, wider rounds win).  For batches that fill the chip several times over
-    // (auto W, >= 32 768 problems) the rounds start narrow and widen -- 4, 4, 8, 16, 16, ... (8, 8, 16, ... for records
-    // staged through LDS) -- so easy searches (pendulum: 4 trials on average) cost 4-8 trials instead of 16 and hard
-    // ones (acrobot: 22) no more than before: 131 072 pendulums 1.24 -> 1.9 M solves/s.  Results do not depend on it.
+    // (auto W, >= 32 768 problems) the rounds start narrow and widen -- 4, 4, 8, 16, 16, ... -- so easy searches (pendulum:
+    // 4 trials on average) cost 4-8 trials instead of 16 and hard ones (acrobot: 22) no more than before: 131 072 pendulums
+    // 1.24 -> 1.9 M solves/s.  Systems whose records are staged through LDS (n > 4: one wave per SIMD, a trial step costs
+    // ~550 instructions) start with 8 and go on in SMALL steps -- 8, 2, 2, 4, 8, 16, 32: a search that fails its first
+    // round usually ends just behind it (the quadcopter batch accepts trial 8 in every problem from iteration 2 on: 10
+    // trials evaluated instead of 16; 8, 8, 16, ... 5.13 ms per search, this 4.23).  Results do not depend on it.
     ws->ls_rounds_n = 0;
     {
         const bool widen = d->n_alpha_parallel == 0 && ws->Bpad >= 32768 && !d->tracking;
-        const int first = ws->n > 4 ? 8 : 4;
+        static const int staged_widths[] = {8, 2, 2, 4, 8, 16, 32};
         int covered = 0;
         while (covered < n_trials) {
             int w = W;
-            if (widen) w = covered < 2 * first ? first : (covered < 4 * first ? 2 * first : 16);
-            if (widen && w > 16) w = 16;
+            if (widen && ws->n > 4) w = staged_widths[ws->ls_rounds_n < 7 ? ws->ls_rounds_n : 6];
+            else if (widen) w = covered < 8 ? 4 : (covered < 16 ? 8 : 16);
             ws->ls_width[ws->ls_rounds_n++] = w;
             covered += w;
         }
