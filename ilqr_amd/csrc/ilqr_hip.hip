@@ -255,7 +255,7 @@ template <class S, int W>
 bool launch_ls(hipStream_t st, const KArgs& a, bool ckpt, bool track)
 {
     const long long waves = a.n_tiles * W;          // tiles * 64 problems * W lanes / 64
-    constexpr int wpb = W == 64 ? 8 : 4;
+    const int wpb = track ? ls_waves_per_block<S, W, true>() : ls_waves_per_block<S, W, false>();
     const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
     if constexpr (!lane_recursion_ok<S>) {
         // m > 4: the split schedule only, and widths the staged rollout's LDS records fit (ilqr_ws_create sees to both)

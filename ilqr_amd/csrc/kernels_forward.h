@@ -300,7 +300,10 @@ struct Staged {
     static constexpr int oX = 0, oU = n, oK = n + m, ok = n + m + m * n;
     static constexpr int qX = (n + W - 1) / W, qU = (m + W - 1) / W, qK = (m * n + W - 1) / W;
     static constexpr int WAVE_DOUBLES = 2 * G * RECP;
-    static constexpr bool use = (n + 2 * m + m * n) > 16 && W >= 8;      // smaller records are prefetched in registers
+    // smaller records are prefetched in registers (or gathered, below).  Narrow rounds (W = 2, 4: 32 or 16 records per wave,
+    // 35 / 18 KB of LDS) run one wave per workgroup; beyond 4 inputs only the widths from 16 up are compiled (launch_ls)
+    static constexpr bool use = (n + 2 * m + m * n) > 16 && W >= 2 && (m <= 4 || W >= 16);
+    static constexpr int WAVES_PER_BLOCK = W == 64 ? 8 : (W >= 8 ? 4 : 1);
 };
 
 template <class S, int W, bool CKPT>
@@ -551,8 +554,14 @@ constexpr int ls_waves_per_simd()
 {
     return S::n > 4 ? 1 : (S::id == ILQR_DYN_ACROBOT_ID ? LS_WAVES_ACROBOT : LS_WAVES_SMALL);   // (4 for cartpole spills 14 VGPRs and gains nothing)
 }
+// waves per workgroup of k_linesearch<S, W>: 4 (8 at W = 64), one where a narrow round stages large records through LDS
+template <class S, int W, bool TRACK = false>
+constexpr int ls_waves_per_block()
+{
+    return Staged<S, W>::use && !TRACK ? Staged<S, W>::WAVES_PER_BLOCK : (W == 64 ? 8 : 4);
+}
 template <class S, int W, bool CKPT, bool TRACK = false>
-__global__ void __launch_bounds__(W == 64 ? 512 : 256, ls_waves_per_simd<S>()) k_linesearch(const KArgs a)
+__global__ void __launch_bounds__((64 * ls_waves_per_block<S, W, TRACK>()), ls_waves_per_simd<S>()) k_linesearch(const KArgs a)
 {
     constexpr int n = S::n, m = S::m, np = S::np;
     constexpr int G = TILE / W;
@@ -598,7 +607,7 @@ __global__ void __launch_bounds__(W == 64 ? 512 : 256, ls_waves_per_simd<S>()) k
     bool okj = false;
     if constexpr (Staged<S, W>::use && !TRACK) {
         // whole wave together (the record loads are shared); lanes without a trial compute on and are ignored
-        __shared__ double sh[(W == 64 ? 8 : 4) * Staged<S, W>::WAVE_DOUBLES];
+        __shared__ double sh[Staged<S, W>::WAVES_PER_BLOCK * Staged<S, W>::WAVE_DOUBLES];
         double* sw = sh + (threadIdx.x >> 6) * Staged<S, W>::WAVE_DOUBLES;
         const long long b_duty = __shfl(b, (lane % G) * W);
         const double alpha = a.alphas[j < a.n_trials ? j : 0];

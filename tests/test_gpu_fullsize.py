@@ -306,10 +306,11 @@ def test_random_bench_batches_against_the_reference_itself(amd, oracle, name):
     print(name, 'GPU-vs-reference | oracle-vs-oracle(FMA) quantiles [50, 90, 100]:', {k_: [list(np.round(v, 13)) for v in vv] for k_, vv in report.items()})
 
 
-@pytest.mark.parametrize('system,B,N', [('pendulum', 65536, 300), ('acrobot', 32768, 200)])
+@pytest.mark.parametrize('system,B,N', [('pendulum', 65536, 300), ('acrobot', 32768, 200), ('quadcopter', 32768, 40)])
 def test_widening_round_schedule_changes_nothing(amd, system, B, N):
-    """auto width on a batch that fills the chip several times over runs rounds of 4, 4, 8, 16, 16, 16 trials instead of
-    fixed-width rounds: a scheduling choice, bit-identical to 59 trials evaluated 32 at a time"""
+    """auto width on a batch that fills the chip several times over runs rounds of 4, 4, 8, 16, 16, 16 trials (8, 2, 2, 4, 8, 16,
+    32 for the quadcopter, whose records are staged through LDS) instead of fixed-width rounds: a scheduling choice,
+    bit-identical to 59 trials evaluated 32 at a time"""
     from ilqr_amd import _lib
     g = golden(system + '_batch')
     rng = np.random.default_rng(17)
