@@ -69,11 +69,12 @@ typedef struct ilqr_desc {
                                      pipeline 2.  1 and 3 give bit-identical results. */
     int32_t overlap;              /* solve() with the four-lane recursion: the accept step of iteration i (parallel over
                                      segments of the horizon, last segments first) and the backward recursion of
-                                     iteration i + 1 (which walks the horizon from its end) run overlapped on two HIP
-                                     streams, in chunks.  0 auto (on when the horizon gives at least 4 chunks of 4 segments of
-                                     64 steps), 1 off, 2 on from two segments up.  Results do not depend on it.  Set 1
-                                     when other PROCESSES use the same GPU: two solves stalled in such rehearsals, none with
-                                     this set to 1; one process per GPU is the supported layout. */
+                                     iteration i + 1 (which walks the horizon from its end) share launches, chunk by chunk:
+                                     one grid holds the recursion over one chunk and the accept step over the chunk below
+                                     it, all on the workspace's one stream (no second stream, no events).  0 auto (on when
+                                     the horizon gives at least 4 chunks of 4 segments of 64 steps), 1 off (separate
+                                     launches), 2 on from two segments up.  Results do not depend on it.  (Rounds 1-2 ran
+                                     the two on two streams joined by events; DESIGN.md section 5 has why that went.) */
     double search_floor;          /* 0.05  the LITERAL in `while learning_rate > 0.05 and armijo_flag == 0` (ilqr.py:185):
                                      trials alpha_j = learning_speed^j run while alpha_j > search_floor.  The reference keeps
                                      it apart from low_learning_rate (:167, used at :204 only); so does this library: a trial
