@@ -1231,7 +1231,7 @@ __global__ void __launch_bounds__(64) k_ltvlqr(const KArgs a)
     }
     // The trajectory is walked row by row: the sin/cos pairs of its angle states are carried from row t + 1 to row t by
     // angle addition on the difference of the two rows (TrigCarry: evaluated afresh at the last row, at every multiple of
-    // the checkpoint interval and whenever two rows are further apart than 2^-4 rad), instead of two range reductions and
+    // the checkpoint interval and whenever two rows are further apart than 3/32 rad), instead of two range reductions and
     // polynomial pairs per row.  A_t and B_t are I + dt * (...): a trig value's last bits reach them scaled by dt.
     TrigCarry<S> trig;
     double xnext[n];

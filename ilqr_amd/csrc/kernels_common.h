@@ -144,16 +144,24 @@ struct KArgs {
 // angle instead of ~55 (range reduction, two minimax kernels, quadrant selects); the acrobot's line-search step drops
 // from ~265 to ~195 instructions.
 //   * d is formed by one subtraction: its rounding error is 2^-53 |d| ~ 1e-19, far below the pair's own rounding.
-//   * |d| <= 2^-4: the neglected Taylor terms are d^11/11! < 2e-21 (sin) and d^10/10! < 3e-19 (cos).  The update is
+//   * |d| <= 3/32 (TRIG_CARRY_MAX_STEP): the neglected Taylor terms are d^11/11! < 2e-19 (sin) and d^10/10! < 2e-17 (cos).  The update is
 //     written s + (small), c + (small): ONE rounding of the pair per step (half an ulp), i.e. a random walk of a few ulp
 //     between re-seeds -- and in f every trig value is scaled by dt before it meets the state (<= 1e-18 of an O(1) state
 //     per step: below the rounding of the state update itself).
 //   * re-seeded with the full evaluation (ilqr_sincos_fast; ocml for huge / non-finite angles) at every multiple of the
 //     checkpoint interval -- so a rollout resumed from a line-search checkpoint (k_accept_lin) sees exactly the pairs
 //     the trial saw: same bits whichever kernel, schedule or segment computes a step -- and at once for any lane whose
-//     step is larger than 2^-4 rad or not finite (diverging trials).
+//     step is larger than 3/32 rad or not finite (diverging trials).
 // The Jacobians A_t, B_t keep their direct evaluations (their entries are not scaled against a large addend).
 // ------------------------------------------------------------------------------------------------
+// Largest |angle step| the recurrence takes before the pair is evaluated afresh.  The series below stop at d^9 (sin) and d^8
+// (cos): at 3/32 rad their truncation errors are d^11/11! = 1.2e-19 and d^10/10! = 1.4e-17, an eighth of the half-ulp of a
+// value near 1 and far below the recurrence's own roundings.  (Round 3: 1/16 before; the cartpole at dt = 0.005 steps past
+// 1/16 rad in ordinary swing-up motion and re-evaluated -- the whole wave waiting -- on 5 % of its line-search steps:
+// 131 072 cartpoles 10.33 -> 10.0 ms of search per pass; the acrobot at dt = 0.001 hardly ever does.)
+#ifndef TRIG_CARRY_MAX_STEP
+#define TRIG_CARRY_MAX_STEP 0.09375
+#endif
 template <class S>
 struct TrigCarry {
     static constexpr int K = S::n_ang;
@@ -187,7 +195,7 @@ struct TrigCarry {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const double d = xn[S::ang(k)] - xo[S::ang(k)];
-                ok = ok && (dont_care || !(__builtin_fabs(d) > 0.0625));
+                ok = ok && (dont_care || !(__builtin_fabs(d) > TRIG_CARRY_MAX_STEP));
                 const double z = d * d;
                 const double sdt = (d * z) * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S4, S3), S2), S1);   // sin d - d
                 const double cm1 = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C4, C3), C2), C1);         // cos d - 1
