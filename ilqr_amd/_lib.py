@@ -269,8 +269,9 @@ class Workspace:
     def sync(self): check(lib().ilqr_ws_sync(self._h))
     def query(self): return check(lib().ilqr_ws_query(self._h))     # 0 idle, 1 work pending (non-blocking)
 
-    def profile(self, enable=True):
-        check(lib().ilqr_ws_profile(self._h, 1 if enable else 0))
+    def profile(self, enable=True, only=None):
+        """HIP-event timing of the passes: every kernel, or only the one named `only` (KERNEL_NAMES)"""
+        check(lib().ilqr_ws_profile(self._h, (2 + KERNEL_NAMES.index(only)) if (enable and only) else (1 if enable else 0)))
 
     def profile_read(self):
         ms = np.zeros(8)

@@ -175,6 +175,7 @@ struct ilqr_ws {
     size_t hbm_bytes;
     int state_rows;
     bool profiling;
+    int prof_only;                           // -1: every kernel id is timed; else only this one (ilqr_ws_profile)
     struct Ev { hipEvent_t a, b; int kid; };
     std::vector<Ev> events;
     double prof_ms[N_KERNEL_IDS];
@@ -222,7 +223,7 @@ int with_system(int sys, F&& fn)
 
 struct ProfScope {
     ilqr_ws* ws; int kid; hipStream_t st; hipEvent_t a, b; bool on;
-    ProfScope(ilqr_ws* w, int k, hipStream_t s) : ws(w), kid(k), st(s), a(nullptr), b(nullptr), on(w && w->profiling)
+    ProfScope(ilqr_ws* w, int k, hipStream_t s) : ws(w), kid(k), st(s), a(nullptr), b(nullptr), on(w && w->profiling && (w->prof_only < 0 || w->prof_only == k))
     {
         if (on) {
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
@@ -921,6 +922,7 @@ int ilqr_ws_create(const ilqr_desc* d, int32_t want_trace, ilqr_ws** out)
     ws->state_rows = ws->N + 1;
     ws->want_trace = want_trace && d->n_iterations > 0;
     ws->profiling = false;
+    ws->prof_only = -1;
     memset(ws->prof_ms, 0, sizeof(ws->prof_ms));
     memset(ws->prof_cnt, 0, sizeof(ws->prof_cnt));
     // alpha table by repeated multiplication (ilqr.py:180,202); the trials are those with alpha > the literal 0.05 of the
@@ -1336,7 +1338,9 @@ int ilqr_ws_profile(ilqr_ws* ws, int32_t enable)
     ws->events.clear();
     memset(ws->prof_ms, 0, sizeof(ws->prof_ms));
     memset(ws->prof_cnt, 0, sizeof(ws->prof_cnt));
+    if (enable < 0 || enable > 1 + N_KERNEL_IDS) return fail(-1, "ilqr_ws_profile: enable must be 0 (off), 1 (every kernel) or 2 + kernel id");
     ws->profiling = enable != 0;
+    ws->prof_only = enable >= 2 ? enable - 2 : -1;
     return 0;
 }
 

@@ -241,7 +241,9 @@ int ilqr_ws_sync(ilqr_ws* ws);
 int ilqr_ws_query(ilqr_ws* ws);
 /* kernel timing with HIP events on the workspace stream.  kernel ids: 0 rollout, 1 backward, 2 linesearch, 3 accept,
  * 4 ltvlqr, 5 forward, 6 cost, 7 linearize.  In the split pipeline backward = k_riccati, accept = k_save_boundaries + k_accept_lin (which also writes A_t, B_t); linesearch = all rounds of a pass.
- * ms[i] = summed duration, launches[i] = count since the last enable. */
+ * ms[i] = summed duration, launches[i] = count since the last enable.  enable: 0 off, 1 every kernel, 2 + id only that kernel
+ * (every timed pass puts two event records -- two barrier packets -- on the stream: timing all passes of the headline solve
+ * costs it 1 %, timing one kernel a fifth of that). */
 int ilqr_ws_profile(ilqr_ws* ws, int32_t enable);
 int ilqr_ws_profile_read(ilqr_ws* ws, double* ms /*8*/, int64_t* launches /*8*/);
 int ilqr_ws_info(ilqr_ws* ws, int32_t* n_alpha_parallel, int32_t* n_trials, int64_t* hbm_bytes);
