@@ -1,6 +1,6 @@
 import os, sys, time
 import numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, ilqr_amd
 from ilqr_amd import _lib
 cfg = bench.acrobot_c2(4096, 0)
